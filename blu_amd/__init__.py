@@ -1,0 +1,8 @@
+"""blu_amd -- MI355X (gfx950) implementation of the factorize hot path of the `blu` crate (rwl/blu).
+
+Product surface: include/blu_hip.h (C ABI, libblu_hip.so) and `blu_amd.BLU`, the host-side mirror of
+the reference's `struct BLU`.  Nothing here imports the CPU oracle (oracle/): that is test
+infrastructure.
+"""
+from . import keys  # noqa: F401
+from .blu import BLU, BluError, build_library, gen_lp_basis, lib  # noqa: F401

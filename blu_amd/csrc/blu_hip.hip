@@ -1,0 +1,839 @@
+// blu_hip.hip -- host side of libblu_hip.so: the C ABI of include/blu_hip.h.
+//
+// Mirrors `struct BLU` (src/blu.rs): BLU::new / factorize (with the internal realloc loop,
+// blu.rs:95-118, 345-377) / get_factors / solve_dense, plus the parameter fields and getters of
+// `struct LU` (src/lu/lu.rs).  All numerical work happens in the HIP kernels of this directory;
+// there is no CPU fallback -- without a gfx950 device blu_hip_new returns NULL.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/blu_hip.h"
+#include "blu_dev.h"
+#include "k_finish.hip"
+#include "k_pivot.hip"
+#include "k_prep.hip"
+#include "k_solve.hip"
+
+#define BLU_STOPPED_STATUS 100 /* debug stepping only */
+
+struct blu_hip {
+    int device;
+    int64_t m, b_nz_hint;
+    // parameters (LU public fields + BLU.realloc_factor)
+    double droptol, abstol, reltol, stretch, compress_thres, sparse_thres, realloc_factor;
+    int64_t nzbias, maxsearch, pad, search_rows;
+    // state
+    int64_t nupdate;   // -1 = None
+    int64_t nfactorize;
+    DevLU D;           // host copy of the device descriptor (device pointers inside)
+    DevLU *dD;         // device copy
+    Scalars hs;        // last downloaded scalars
+    FinishOut O;       // device output buffers of get_factors
+    FinishOut *dO;
+    int64_t out_lcap, out_ucap;
+    // owned device copies of the caller's B (blu_hip_factorize with host arrays)
+    unsigned long long *ob_begin, *ob_end, *ob_i;
+    double *ob_x;
+    int64_t ob_mcap, ob_nzcap;
+    // solve workspace
+    double *d_rhs, *d_lhs;
+    int *lvl_l, *lvl_u;
+    // timing
+    hipStream_t stream;
+    hipEvent_t ev[4];
+    double t_total, t_pivot;
+    int relaunches;
+    int block_threads; // workgroup size of the pivot kernel
+    std::string err;
+    int64_t stop_at;   // debug: -1 off
+};
+
+// ---------------------------------------------------------------------------------------------
+static bool hip_ok(blu_hip *h, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    if (h) h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(h, call)                                \
+    do {                                                \
+        if (!hip_ok((h), (call), #call)) return false;  \
+    } while (0)
+
+template <class T> static bool dalloc(blu_hip *h, T **p, size_t n)
+{
+    *p = nullptr;
+    return hip_ok(h, hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc");
+}
+template <class T> static void dfree(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+// grow a device array keeping the first `keep` elements
+template <class T> static bool dgrow(blu_hip *h, T **p, size_t keep, size_t n)
+{
+    T *q;
+    if (!dalloc(h, &q, n)) return false;
+    if (*p && keep) {
+        if (!hip_ok(h, hipMemcpy(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice), "hipMemcpy d2d")) return false;
+    }
+    if (*p) (void)hipFree((void *)*p);
+    *p = q;
+    return true;
+}
+
+static const int64_t kIntMax = 0x7ffffff0;
+
+static void free_all(blu_hip *h)
+{
+    DevLU &D = h->D;
+    dfree(D.bc_ptr); dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_ptr); dfree(D.bt_idx); dfree(D.bt_val);
+    dfree(D.pinv); dfree(D.qinv); dfree(D.prow); dfree(D.pcol);
+    dfree(D.cbeg); dfree(D.clen); dfree(D.ccap); dfree(D.cidx); dfree(D.cval);
+    dfree(D.rbeg); dfree(D.rlen); dfree(D.rcap); dfree(D.ridx); dfree(D.colmax);
+    dfree(D.cflink); dfree(D.cblink); dfree(D.rflink); dfree(D.rblink);
+    dfree(D.rowmark); dfree(D.colmark); dfree(D.tnew); dfree(D.tnewr); dfree(D.txrj); dfree(D.tmask);
+    dfree(D.gwork); dfree(D.iw0); dfree(D.iw1); dfree(D.iw2);
+    dfree(D.lbeg); dfree(D.ubeg); dfree(D.lidx); dfree(D.uidx); dfree(D.lval); dfree(D.uval);
+    dfree(D.s);
+    dfree(h->dD); dfree(h->dO);
+    dfree(h->O.rowperm); dfree(h->O.colperm); dfree(h->O.l_colptr); dfree(h->O.l_rowidx); dfree(h->O.l_value);
+    dfree(h->O.u_colptr); dfree(h->O.u_rowidx); dfree(h->O.u_value);
+    dfree(h->ob_begin); dfree(h->ob_end); dfree(h->ob_i); dfree(h->ob_x);
+    dfree(h->d_rhs); dfree(h->d_lhs); dfree(h->lvl_l); dfree(h->lvl_u);
+}
+
+static bool upload_desc(blu_hip *h)
+{
+    DevLU &D = h->D;
+    D.m = (int)h->m;
+    D.nzbias = (int)h->nzbias;
+    D.maxsearch = (int)std::min<int64_t>(h->maxsearch, kIntMax);
+    D.pad = (int)h->pad;
+    D.search_rows = (int)h->search_rows;
+    D.droptol = h->droptol;
+    D.abstol = h->abstol;
+    D.reltol = h->reltol;
+    D.stretch = h->stretch;
+    HIP_TRY(h, hipMemcpy(h->dD, &D, sizeof(DevLU), hipMemcpyHostToDevice));
+    return true;
+}
+static bool download_scalars(blu_hip *h)
+{
+    HIP_TRY(h, hipMemcpy(&h->hs, h->D.s, sizeof(Scalars), hipMemcpyDeviceToHost));
+    return true;
+}
+static bool set_status(blu_hip *h, int st)
+{
+    HIP_TRY(h, hipMemcpy(&h->D.s->status, &st, sizeof(int), hipMemcpyHostToDevice));
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BLU::new -- src/blu.rs:61, LU::new src/lu/lu.rs:243-319
+// ---------------------------------------------------------------------------------------------
+extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
+{
+    if (m < 0 || b_nz < 0 || m > kIntMax / 2 - 4 || b_nz > kIntMax / 8) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return nullptr; // kernels are built for gfx950 only
+
+    blu_hip *h = new blu_hip();
+    h->device = device;
+    h->m = m;
+    h->b_nz_hint = b_nz;
+    // defaults, lu.rs:249-259 and blu.rs:68
+    h->droptol = 1e-20;
+    h->abstol = 1e-14;
+    h->reltol = 0.1;
+    h->nzbias = 1;
+    h->maxsearch = 3;
+    h->pad = 4;
+    h->stretch = 0.3;
+    h->compress_thres = 0.5;
+    h->sparse_thres = 0.05;
+    h->search_rows = 0;
+    h->realloc_factor = 1.5;
+    h->nupdate = -1;
+    h->nfactorize = 0;
+    h->stop_at = -1;
+    h->block_threads = 1024;
+    memset(&h->D, 0, sizeof(DevLU));
+    memset(&h->hs, 0, sizeof(Scalars));
+    memset(&h->O, 0, sizeof(FinishOut));
+
+    DevLU &D = h->D;
+    const size_t M = (size_t)m;
+    // The reference starts with l_mem = u_mem = w_mem = b_nz and grows on demand (blu.rs:345-377).
+    // HBM is plentiful: start roomy so that the pivot loop rarely has to leave the device.
+    D.nzcap = (int)std::max<int64_t>(b_nz, 1);
+    D.lcap = (int)std::min<int64_t>(4 * b_nz + 4 * m + 64, kIntMax);
+    D.ucap = D.lcap;
+    D.carena_cap = (int)std::min<int64_t>(6 * b_nz + 8 * m + 64, kIntMax);
+    D.rarena_cap = D.carena_cap;
+    bool ok = true;
+    ok = ok && dalloc(h, &D.bc_ptr, M + 1) && dalloc(h, &D.bc_idx, D.nzcap) && dalloc(h, &D.bc_val, D.nzcap);
+    ok = ok && dalloc(h, &D.bt_ptr, M + 1) && dalloc(h, &D.bt_idx, D.nzcap) && dalloc(h, &D.bt_val, D.nzcap);
+    ok = ok && dalloc(h, &D.pinv, M) && dalloc(h, &D.qinv, M) && dalloc(h, &D.prow, M + 1) && dalloc(h, &D.pcol, M + 1);
+    ok = ok && dalloc(h, &D.cbeg, M) && dalloc(h, &D.clen, M) && dalloc(h, &D.ccap, M);
+    ok = ok && dalloc(h, &D.cidx, D.carena_cap) && dalloc(h, &D.cval, D.carena_cap);
+    ok = ok && dalloc(h, &D.rbeg, M) && dalloc(h, &D.rlen, M) && dalloc(h, &D.rcap, M) && dalloc(h, &D.ridx, D.rarena_cap);
+    ok = ok && dalloc(h, &D.colmax, M);
+    ok = ok && dalloc(h, &D.cflink, 2 * M + 2) && dalloc(h, &D.cblink, 2 * M + 2);
+    ok = ok && dalloc(h, &D.rflink, 2 * M + 2) && dalloc(h, &D.rblink, 2 * M + 2);
+    ok = ok && dalloc(h, &D.rowmark, M) && dalloc(h, &D.colmark, M);
+    ok = ok && dalloc(h, &D.tnew, M + 2) && dalloc(h, &D.tnewr, M + 2) && dalloc(h, &D.txrj, M + 2) && dalloc(h, &D.tmask, M + 2);
+    ok = ok && dalloc(h, &D.gwork, 16 * (M + 1));
+    ok = ok && dalloc(h, &D.iw0, M + 2) && dalloc(h, &D.iw1, M + 2) && dalloc(h, &D.iw2, M + 2);
+    ok = ok && dalloc(h, &D.lbeg, M + 1) && dalloc(h, &D.ubeg, M + 1);
+    ok = ok && dalloc(h, &D.lidx, D.lcap) && dalloc(h, &D.lval, D.lcap) && dalloc(h, &D.uidx, D.ucap) && dalloc(h, &D.uval, D.ucap);
+    ok = ok && dalloc(h, &D.s, 1) && dalloc(h, &h->dD, 1) && dalloc(h, &h->dO, 1);
+    ok = ok && dalloc(h, &h->O.rowperm, M) && dalloc(h, &h->O.colperm, M) && dalloc(h, &h->O.l_colptr, M + 1) && dalloc(h, &h->O.u_colptr, M + 1);
+    ok = ok && dalloc(h, &h->d_rhs, M) && dalloc(h, &h->d_lhs, M) && dalloc(h, &h->lvl_l, M + 2) && dalloc(h, &h->lvl_u, M + 2);
+    if (ok) ok = hip_ok(h, hipMemset(D.gwork, 0, 16 * (M + 1) * sizeof(double)), "hipMemset");
+    if (ok) ok = hip_ok(h, hipStreamCreate(&h->stream), "hipStreamCreate");
+    for (int k = 0; ok && k < 4; k++) ok = hip_ok(h, hipEventCreate(&h->ev[k]), "hipEventCreate");
+    if (!ok) {
+        free_all(h);
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void blu_hip_free(blu_hip *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_all(h);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int k = 0; k < 4; k++)
+        if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    delete h;
+}
+
+extern "C" int blu_hip_set_param(blu_hip *h, int key, double v)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    switch (key) {
+    case BLU_PARAM_DROPTOL: h->droptol = v; break;
+    case BLU_PARAM_ABSTOL: h->abstol = v; break;
+    case BLU_PARAM_RELTOL: h->reltol = v; break;
+    case BLU_PARAM_NZBIAS: h->nzbias = v < 0 ? -1 : (int64_t)v; break;
+    case BLU_PARAM_MAXSEARCH: h->maxsearch = (int64_t)v; break;
+    case BLU_PARAM_PAD: h->pad = (int64_t)v; break;
+    case BLU_PARAM_STRETCH: h->stretch = v; break;
+    case BLU_PARAM_COMPRESS_THRES: h->compress_thres = v; break;
+    case BLU_PARAM_SPARSE_THRES: h->sparse_thres = v; break;
+    case BLU_PARAM_SEARCH_ROWS: h->search_rows = (int64_t)v; break;
+    case BLU_PARAM_REALLOC_FACTOR: h->realloc_factor = v; break;
+    default: return BLU_ERROR_INVALID_ARGUMENT;
+    }
+    return BLU_OK;
+}
+extern "C" double blu_hip_get_param(const blu_hip *h, int key)
+{
+    if (!h) return NAN;
+    switch (key) {
+    case BLU_PARAM_DROPTOL: return h->droptol;
+    case BLU_PARAM_ABSTOL: return h->abstol;
+    case BLU_PARAM_RELTOL: return h->reltol;
+    case BLU_PARAM_NZBIAS: return (double)h->nzbias;
+    case BLU_PARAM_MAXSEARCH: return (double)h->maxsearch;
+    case BLU_PARAM_PAD: return (double)h->pad;
+    case BLU_PARAM_STRETCH: return h->stretch;
+    case BLU_PARAM_COMPRESS_THRES: return h->compress_thres;
+    case BLU_PARAM_SPARSE_THRES: return h->sparse_thres;
+    case BLU_PARAM_SEARCH_ROWS: return (double)h->search_rows;
+    case BLU_PARAM_REALLOC_FACTOR: return h->realloc_factor;
+    default: return NAN;
+    }
+}
+
+extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
+{
+    if (!h) return NAN;
+    const Scalars &s = h->hs;
+    switch (key) {
+    case BLU_STAT_M: return (double)h->m;
+    case BLU_STAT_NUPDATE: return (double)h->nupdate;
+    case BLU_STAT_NFACTORIZE: return (double)h->nfactorize;
+    case BLU_STAT_L_NZ: return (double)s.l_nz;
+    case BLU_STAT_U_NZ: return (double)s.u_nz;
+    case BLU_STAT_MIN_PIVOT: return s.min_pivot;
+    case BLU_STAT_MAX_PIVOT: return s.max_pivot;
+    case BLU_STAT_CONDEST_L: return s.condest_l;
+    case BLU_STAT_CONDEST_U: return s.condest_u;
+    case BLU_STAT_NORM_L: return s.norm_l;
+    case BLU_STAT_NORM_U: return s.norm_u;
+    case BLU_STAT_NORMEST_L_INV: return s.normest_l_inv;
+    case BLU_STAT_NORMEST_U_INV: return s.normest_u_inv;
+    case BLU_STAT_ONENORM: return s.onenorm;
+    case BLU_STAT_INFNORM: return s.infnorm;
+    case BLU_STAT_RESIDUAL_TEST: return s.residual_test;
+    case BLU_STAT_MATRIX_NZ: return (double)s.matrix_nz;
+    case BLU_STAT_RANK: return (double)s.rank;
+    case BLU_STAT_BUMP_SIZE: return (double)s.bump_size;
+    case BLU_STAT_BUMP_NZ: return (double)s.bump_nz;
+    case BLU_STAT_NSEARCH_PIVOT: return (double)s.nsearch_pivot;
+    case BLU_STAT_NEXPAND: return (double)s.nexpand;
+    case BLU_STAT_NGARBAGE: return (double)s.ngarbage;
+    case BLU_STAT_FACTOR_FLOPS: return (double)s.factor_flops;
+    case BLU_STAT_TIME_FACTORIZE: return h->t_total;
+    case BLU_STAT_TIME_SINGLETONS: return 0.0;
+    case BLU_STAT_TIME_SEARCH_PIVOT: return 0.0;
+    case BLU_STAT_TIME_ELIM_PIVOT: return h->t_pivot;
+    case BLU_STAT_UPDATE_COST_DENOM: // factorize.rs:160-166
+        return 250.0 * (0.04 * (double)h->m + 0.07 * (double)s.matrix_nz + 0.20 * (double)s.bump_nz +
+                        0.20 * (double)s.nsearch_pivot + 0.008 * (double)s.factor_flops);
+    case BLU_STAT_RANKDEF: return (double)s.rankdef;
+    case BLU_STAT_L_MEM: return (double)h->D.lcap;
+    case BLU_STAT_U_MEM: return (double)h->D.ucap;
+    case BLU_STAT_W_MEM: return (double)h->D.carena_cap + (double)h->D.rarena_cap;
+    case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;
+    case BLU_STAT_DEV_TIME_TOTAL: return h->t_total;
+    case BLU_STAT_DEV_RELAUNCHES: return (double)h->relaunches;
+    case 50: return (double)s.d3_hits;       // BLU_STAT_DEV_D3_HITS
+    case 51: return (double)s.npivot_kind[0];
+    case 52: return (double)s.npivot_kind[1];
+    case 53: return (double)s.npivot_kind[2];
+    case 54: return (double)s.npivot_kind[3];
+    case 55: return (double)s.npivot_kind[4];
+    case 56: return (double)s.npivot_kind[5];
+    case 57: return (double)s.err_line;
+    case 58: return (double)s.status;
+    default: return NAN;
+    }
+}
+
+extern "C" const char *blu_hip_last_error(const blu_hip *h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" const char *blu_hip_version(void) { return "blu_hip 0.1 (gfx950)"; }
+extern "C" int blu_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// memory growth (the device-side counterpart of lu_realloc_obj, blu.rs:345-377)
+// ---------------------------------------------------------------------------------------------
+static int64_t grown(blu_hip *h, int64_t cap, int64_t need_extra)
+{
+    const double f = std::max(1.0, h->realloc_factor);
+    int64_t n = (int64_t)((double)(cap + need_extra) * f) + 64;
+    return std::min<int64_t>(n, kIntMax);
+}
+static bool grow_l(blu_hip *h, int need)
+{
+    DevLU &D = h->D;
+    const int64_t n = grown(h, D.lcap, need);
+    if (n <= D.lcap) { h->err = "L storage limit (2^31 entries) reached"; return false; }
+    if (!dgrow(h, &D.lidx, (size_t)h->hs.lused, (size_t)n) || !dgrow(h, &D.lval, (size_t)h->hs.lused, (size_t)n)) return false;
+    D.lcap = (int)n;
+    return true;
+}
+static bool grow_u(blu_hip *h, int need)
+{
+    DevLU &D = h->D;
+    const int64_t n = grown(h, D.ucap, need);
+    if (n <= D.ucap) { h->err = "U storage limit (2^31 entries) reached"; return false; }
+    if (!dgrow(h, &D.uidx, (size_t)h->hs.uused, (size_t)n) || !dgrow(h, &D.uval, (size_t)h->hs.uused, (size_t)n)) return false;
+    D.ucap = (int)n;
+    return true;
+}
+// compact one file into a new, larger arena (file_compress + realloc)
+static bool compact_file(blu_hip *h, int which, int need)
+{
+    DevLU &D = h->D;
+    const int64_t oldcap = which ? D.rarena_cap : D.carena_cap;
+    const int64_t n = grown(h, oldcap, need);
+    if (n <= oldcap) { h->err = "arena limit (2^31 entries) reached"; return false; }
+    int *nidx = nullptr;
+    double *nval = nullptr;
+    if (!dalloc(h, &nidx, (size_t)n)) return false;
+    if (!which && !dalloc(h, &nval, (size_t)n)) return false;
+    int **d_pi = nullptr;
+    double **d_pv = nullptr;
+    int *d_cap = nullptr;
+    if (!dalloc(h, &d_pi, 1) || !dalloc(h, &d_pv, 1) || !dalloc(h, &d_cap, 1)) return false;
+    const int capi = (int)n;
+    HIP_TRY(h, hipMemcpy(d_pi, &nidx, sizeof(int *), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_pv, &nval, sizeof(double *), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_cap, &capi, sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->dD, which, d_pi, d_pv, d_cap);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dfree(d_pi); dfree(d_pv); dfree(d_cap);
+    if (which) {
+        dfree(D.ridx);
+        D.ridx = nidx;
+        D.rarena_cap = capi;
+    } else {
+        dfree(D.cidx);
+        dfree(D.cval);
+        D.cidx = nidx;
+        D.cval = nval;
+        D.carena_cap = capi;
+    }
+    return upload_desc(h);
+}
+
+static bool ensure_out(blu_hip *h, int64_t ln, int64_t un)
+{
+    if (ln > h->out_lcap) {
+        dfree(h->O.l_rowidx); dfree(h->O.l_value);
+        if (!dalloc(h, &h->O.l_rowidx, (size_t)ln) || !dalloc(h, &h->O.l_value, (size_t)ln)) return false;
+        h->out_lcap = ln;
+    }
+    if (un > h->out_ucap) {
+        dfree(h->O.u_rowidx); dfree(h->O.u_value);
+        if (!dalloc(h, &h->O.u_rowidx, (size_t)un) || !dalloc(h, &h->O.u_value, (size_t)un)) return false;
+        h->out_ucap = un;
+    }
+    HIP_TRY(h, hipMemcpy(h->dO, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the factorize driver: factorize() (src/factorize.rs:34-182) + BLU::factorize's realloc loop
+// ---------------------------------------------------------------------------------------------
+static int finish_stage(blu_hip *h);
+
+// pivot loop (continued until done / stopped), then build + read-out
+static int pivot_stage(blu_hip *h)
+{
+    DevLU &D = h->D;
+    for (int iter = 0; iter < 200; iter++) {
+        (void)hipEventRecord(h->ev[2], h->stream);
+        hipLaunchKernelGGL(k_pivot_loop, dim3(1), dim3(h->block_threads), 0, h->stream, h->dD, (int)h->stop_at);
+        (void)hipEventRecord(h->ev[3], h->stream);
+        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_pivot_loop")) return BLU_ERROR_DEVICE;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev[2], h->ev[3]);
+        h->t_pivot += 1e-3 * ms;
+        h->relaunches++;
+        if (!download_scalars(h)) return BLU_ERROR_DEVICE;
+        const int st = h->hs.status;
+        if (st == ST_DONE) return finish_stage(h);
+        if (st == ST_STOPPED) return BLU_STOPPED_STATUS;
+        bool ok = true;
+        if (st == ST_NEED_L) ok = grow_l(h, h->hs.need) && upload_desc(h);
+        else if (st == ST_NEED_U) ok = grow_u(h, h->hs.need) && upload_desc(h);
+        else if (st == ST_NEED_CW) ok = compact_file(h, 0, h->hs.need);
+        else if (st == ST_NEED_RW) ok = compact_file(h, 1, h->hs.need);
+        else {
+            char buf[128];
+            snprintf(buf, sizeof buf, "pivot loop failed: device status %d at k_pivot.hip/blu_dev.h line %d", st, h->hs.err_line);
+            h->err = buf;
+            return BLU_ERROR_DEVICE;
+        }
+        if (!ok) return h->err.find("hipMalloc") != std::string::npos ? BLU_ERROR_OUT_OF_MEMORY : BLU_ERROR_DEVICE;
+        if (!set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
+    }
+    h->err = "pivot loop: too many relaunches";
+    return BLU_ERROR_DEVICE;
+}
+
+static int finish_stage(blu_hip *h)
+{
+    if (!ensure_out(h, (int64_t)h->hs.lused + h->m, (int64_t)h->hs.uused + h->m)) return BLU_ERROR_OUT_OF_MEMORY;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO);
+    (void)hipEventRecord(h->ev[1], h->stream);
+    if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_finish")) return BLU_ERROR_DEVICE;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    h->t_total = 1e-3 * ms;
+    if (!download_scalars(h)) return BLU_ERROR_DEVICE;
+    if (h->hs.status != ST_DONE) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "finish failed: device status %d line %d", h->hs.status, h->hs.err_line);
+        h->err = buf;
+        return BLU_ERROR_DEVICE;
+    }
+    // factorization successfully finished (factorize.rs:114-119)
+    h->nupdate = 0;
+    h->nfactorize++;
+    return h->hs.rank < h->m ? BLU_WARNING_SINGULAR_MATRIX : BLU_OK;
+}
+
+static int factorize_device_impl(blu_hip *h, const uint64_t *d_b_begin, const uint64_t *d_b_end,
+                                 const uint64_t *d_b_i, const double *d_b_x, uint64_t b_i_len)
+{
+    DevLU &D = h->D;
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    h->err.clear();
+    h->nupdate = -1; // lu.reset(): invalidate (lu.rs:331)
+    h->t_pivot = 0;
+    h->t_total = 0;
+    h->relaunches = 0;
+    D.b_begin = (const unsigned long long *)d_b_begin;
+    D.b_end = (const unsigned long long *)d_b_end;
+    D.b_i = (const unsigned long long *)d_b_i;
+    D.b_x = d_b_x;
+    D.b_i_len = (long long)b_i_len;
+    if (h->m == 0) { // nothing to do; the reference would run its loops over empty ranges
+        memset(&h->hs, 0, sizeof(Scalars));
+        h->nupdate = 0;
+        h->nfactorize++;
+        return BLU_OK;
+    }
+    (void)hipEventRecord(h->ev[0], h->stream);
+    for (int attempt = 0; attempt < 64; attempt++) {
+        Scalars z;
+        memset(&z, 0, sizeof z);
+        z.status = ST_RUNNING;
+        z.pivot_row = z.pivot_col = -1;
+        if (!hip_ok(h, hipMemcpy(D.s, &z, sizeof z, hipMemcpyHostToDevice), "scalars reset") || !upload_desc(h)) return BLU_ERROR_DEVICE;
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, h->stream, h->dD);
+        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_prep") || !download_scalars(h)) return BLU_ERROR_DEVICE;
+        int st = h->hs.status;
+        if (st == ST_INVALID_ARG) return BLU_ERROR_INVALID_ARGUMENT;
+        if (st == ST_NEED_CW) { // packed copies of B too small
+            const int64_t n = std::min<int64_t>((int64_t)h->hs.need + 64, kIntMax);
+            dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_idx); dfree(D.bt_val);
+            if (!dalloc(h, &D.bc_idx, n) || !dalloc(h, &D.bc_val, n) || !dalloc(h, &D.bt_idx, n) || !dalloc(h, &D.bt_val, n)) return BLU_ERROR_OUT_OF_MEMORY;
+            D.nzcap = (int)n;
+            continue;
+        }
+        if (st == ST_NEED_L || st == ST_NEED_U) {
+            h->hs.lused = h->hs.uused = 0;
+            if (!(st == ST_NEED_L ? grow_l(h, h->hs.need) : grow_u(h, h->hs.need))) return BLU_ERROR_OUT_OF_MEMORY;
+            continue;
+        }
+        if (st != ST_RUNNING) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "prep failed: device status %d line %d", st, h->hs.err_line);
+            h->err = buf;
+            return BLU_ERROR_DEVICE;
+        }
+        // setup_bump; arenas are grown until the bump fits (setup_bump.rs:105-113)
+        bool again = false;
+        for (int a2 = 0; a2 < 64; a2++) {
+            hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, h->stream, h->dD);
+            if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_setup") || !download_scalars(h)) return BLU_ERROR_DEVICE;
+            st = h->hs.status;
+            if (st == ST_NEED_CW || st == ST_NEED_RW) {
+                const int64_t n = grown(h, 2 * (int64_t)h->hs.need, 0);
+                if (st == ST_NEED_CW) {
+                    dfree(D.cidx); dfree(D.cval);
+                    if (!dalloc(h, &D.cidx, n) || !dalloc(h, &D.cval, n)) return BLU_ERROR_OUT_OF_MEMORY;
+                    D.carena_cap = (int)n;
+                } else {
+                    dfree(D.ridx);
+                    if (!dalloc(h, &D.ridx, n)) return BLU_ERROR_OUT_OF_MEMORY;
+                    D.rarena_cap = (int)n;
+                }
+                if (!upload_desc(h) || !set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
+                continue;
+            }
+            break;
+        }
+        if (again) continue;
+        if (st != ST_RUNNING) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "setup failed: device status %d line %d", st, h->hs.err_line);
+            h->err = buf;
+            return BLU_ERROR_DEVICE;
+        }
+        return pivot_stage(h);
+    }
+    h->err = "factorize: too many reallocation rounds";
+    return BLU_ERROR_DEVICE;
+}
+
+extern "C" int blu_hip_factorize_device(blu_hip *h, const uint64_t *d_b_begin, const uint64_t *d_b_end,
+                                        const uint64_t *d_b_i, const double *d_b_x, uint64_t b_i_len)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->m > 0 && (!d_b_begin || !d_b_end || (b_i_len && (!d_b_i || !d_b_x)))) return BLU_ERROR_ARGUMENT_MISSING;
+    return factorize_device_impl(h, d_b_begin, d_b_end, d_b_i, d_b_x, b_i_len);
+}
+
+// BLU::factorize with host arrays: copy B to the device, then as above
+extern "C" int blu_hip_factorize(blu_hip *h, const uint64_t *b_begin, const uint64_t *b_end,
+                                 const uint64_t *b_i, const double *b_x, uint64_t b_i_len)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->m > 0 && (!b_begin || !b_end || (b_i_len && (!b_i || !b_x)))) return BLU_ERROR_ARGUMENT_MISSING;
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    const size_t M = (size_t)h->m, NZ = (size_t)b_i_len;
+    if ((int64_t)M > h->ob_mcap) {
+        dfree(h->ob_begin); dfree(h->ob_end);
+        if (!dalloc(h, &h->ob_begin, M) || !dalloc(h, &h->ob_end, M)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->ob_mcap = (int64_t)M;
+    }
+    if ((int64_t)NZ > h->ob_nzcap) {
+        dfree(h->ob_i); dfree(h->ob_x);
+        if (!dalloc(h, &h->ob_i, NZ) || !dalloc(h, &h->ob_x, NZ)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->ob_nzcap = (int64_t)NZ;
+    }
+    bool ok = true;
+    if (M) ok = ok && hip_ok(h, hipMemcpy(h->ob_begin, b_begin, M * 8, hipMemcpyHostToDevice), "h2d b_begin");
+    if (M) ok = ok && hip_ok(h, hipMemcpy(h->ob_end, b_end, M * 8, hipMemcpyHostToDevice), "h2d b_end");
+    if (NZ) ok = ok && hip_ok(h, hipMemcpy(h->ob_i, b_i, NZ * 8, hipMemcpyHostToDevice), "h2d b_i");
+    if (NZ) ok = ok && hip_ok(h, hipMemcpy(h->ob_x, b_x, NZ * 8, hipMemcpyHostToDevice), "h2d b_x");
+    if (!ok) return BLU_ERROR_DEVICE;
+    return factorize_device_impl(h, (const uint64_t *)h->ob_begin, (const uint64_t *)h->ob_end,
+                                 (const uint64_t *)h->ob_i, h->ob_x, b_i_len);
+}
+
+// BLU::get_factors -- src/blu.rs:139, get_factors.rs:48-180
+extern "C" int blu_hip_get_factors(blu_hip *h, int64_t *rowperm, int64_t *colperm,
+                                   int64_t *l_colptr, int64_t *l_rowidx, double *l_value,
+                                   int64_t *u_colptr, int64_t *u_rowidx, double *u_value)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->nupdate != 0) return BLU_ERROR_INVALID_CALL; // get_factors.rs:59
+    if (h->m == 0) {
+        if (l_colptr) l_colptr[0] = 0;
+        if (u_colptr) u_colptr[0] = 0;
+        return BLU_OK;
+    }
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    const size_t M = (size_t)h->m;
+    const size_t ln = (size_t)h->hs.l_nz + M, un = (size_t)h->hs.u_nz + M;
+    bool ok = true;
+    if (rowperm) ok = ok && hip_ok(h, hipMemcpy(rowperm, h->O.rowperm, M * 8, hipMemcpyDeviceToHost), "d2h rowperm");
+    if (colperm) ok = ok && hip_ok(h, hipMemcpy(colperm, h->O.colperm, M * 8, hipMemcpyDeviceToHost), "d2h colperm");
+    if (l_colptr && l_rowidx && l_value) {
+        ok = ok && hip_ok(h, hipMemcpy(l_colptr, h->O.l_colptr, (M + 1) * 8, hipMemcpyDeviceToHost), "d2h l_colptr");
+        ok = ok && hip_ok(h, hipMemcpy(l_rowidx, h->O.l_rowidx, ln * 8, hipMemcpyDeviceToHost), "d2h l_rowidx");
+        ok = ok && hip_ok(h, hipMemcpy(l_value, h->O.l_value, ln * 8, hipMemcpyDeviceToHost), "d2h l_value");
+    }
+    if (u_colptr && u_rowidx && u_value) {
+        ok = ok && hip_ok(h, hipMemcpy(u_colptr, h->O.u_colptr, (M + 1) * 8, hipMemcpyDeviceToHost), "d2h u_colptr");
+        ok = ok && hip_ok(h, hipMemcpy(u_rowidx, h->O.u_rowidx, un * 8, hipMemcpyDeviceToHost), "d2h u_rowidx");
+        ok = ok && hip_ok(h, hipMemcpy(u_value, h->O.u_value, un * 8, hipMemcpyDeviceToHost), "d2h u_value");
+    }
+    return ok ? BLU_OK : BLU_ERROR_DEVICE;
+}
+
+// BLU::solve_dense -- src/blu.rs:182, lu/solve_dense.rs:7-120 (fresh factorization: nforrest == 0)
+extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, char trans)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->nupdate < 0) return BLU_ERROR_INVALID_CALL; // solve_dense.rs:25-27
+    if (!rhs || !lhs) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->m == 0) return BLU_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    const size_t M = (size_t)h->m;
+    if (!hip_ok(h, hipMemcpy(h->d_rhs, rhs, M * 8, hipMemcpyHostToDevice), "h2d rhs")) return BLU_ERROR_DEVICE;
+    const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
+    hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO, h->d_rhs, h->d_lhs, tr);
+    if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_dense")) return BLU_ERROR_DEVICE;
+    if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
+    return BLU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch of independent factorizations on one device, one workgroup per handle
+// ---------------------------------------------------------------------------------------------
+extern "C" int blu_hip_factorize_batch(blu_hip **hs, int n, const uint64_t *const *b_begin,
+                                       const uint64_t *const *b_end, const uint64_t *const *b_i,
+                                       const double *const *b_x, const uint64_t *b_i_len,
+                                       int inputs_on_device, int *status)
+{
+    // Round 1: handles are processed through the single-matrix driver on their own streams is NOT
+    // implemented yet; this entry runs them back to back (correct, not concurrent).
+    if (!hs || n < 0) return BLU_ERROR_ARGUMENT_MISSING;
+    int worst = BLU_OK;
+    for (int k = 0; k < n; k++) {
+        int st = inputs_on_device ? blu_hip_factorize_device(hs[k], b_begin[k], b_end[k], b_i[k], b_x[k], b_i_len[k])
+                                  : blu_hip_factorize(hs[k], b_begin[k], b_end[k], b_i[k], b_x[k], b_i_len[k]);
+        if (status) status[k] = st;
+        if (st < 0) worst = st;
+        else if (st > worst && worst >= 0) worst = st;
+    }
+    return worst;
+}
+
+// ---------------------------------------------------------------------------------------------
+// debug / test hooks (step-wise comparison with the oracle); not part of the drop-in surface
+// ---------------------------------------------------------------------------------------------
+extern "C" int blu_hip_dbg_set_stop(blu_hip *h, int64_t stop_at)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    h->stop_at = stop_at;
+    return BLU_OK;
+}
+extern "C" int blu_hip_dbg_set_block(blu_hip *h, int threads)
+{
+    if (!h || threads < 64 || threads > 1024 || (threads & 63)) return BLU_ERROR_INVALID_ARGUMENT;
+    h->block_threads = threads;
+    return BLU_OK;
+}
+// continue a factorization that returned 100 (stopped)
+extern "C" int blu_hip_dbg_continue(blu_hip *h, int64_t stop_at)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    h->stop_at = stop_at;
+    if (!download_scalars(h)) return BLU_ERROR_DEVICE;
+    if (h->hs.status != ST_STOPPED) return BLU_ERROR_INVALID_CALL;
+    if (!set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
+    return pivot_stage(h);
+}
+template <class T> static bool d2h_vec(blu_hip *h, std::vector<T> &v, const T *d, size_t n)
+{
+    v.resize(std::max<size_t>(n, 1));
+    if (!n) return true;
+    return hip_ok(h, hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost), "d2h dbg");
+}
+// which: 0 column-file entries, 1 row-file entries, 2 L entries so far, 3 U entries so far
+extern "C" int64_t blu_hip_dbg_count(blu_hip *h, int which)
+{
+    if (!h) return -1;
+    (void)hipSetDevice(h->device);
+    if (!download_scalars(h)) return -1;
+    if (which == 2) return h->hs.lused;
+    if (which == 3) return h->hs.uused;
+    std::vector<int> len;
+    if (!d2h_vec(h, len, which ? h->D.rlen : h->D.clen, (size_t)h->m)) return -1;
+    int64_t n = 0;
+    for (int64_t k = 0; k < h->m; k++) n += len[k];
+    return n;
+}
+// same layout as oracle/orc_debug.c: orc_dbg_active_state
+extern "C" int blu_hip_dbg_active_state(blu_hip *h, int64_t *colptr, int64_t *colidx, double *colval,
+                                        int64_t *rowptr, int64_t *rowidx, double *colmax, int64_t *pinv, int64_t *qinv,
+                                        int64_t *col_flink, int64_t *col_blink, int64_t *row_flink, int64_t *row_blink)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    (void)hipSetDevice(h->device);
+    const size_t M = (size_t)h->m;
+    DevLU &D = h->D;
+    std::vector<int> cbeg, clen, rbeg, rlen, cidx, ridx, pi, qi, cf, cb, rf, rb;
+    std::vector<double> cval;
+    bool ok = d2h_vec(h, cbeg, D.cbeg, M) && d2h_vec(h, clen, D.clen, M) && d2h_vec(h, rbeg, D.rbeg, M) && d2h_vec(h, rlen, D.rlen, M);
+    ok = ok && d2h_vec(h, cidx, D.cidx, (size_t)D.carena_cap) && d2h_vec(h, cval, D.cval, (size_t)D.carena_cap) && d2h_vec(h, ridx, D.ridx, (size_t)D.rarena_cap);
+    ok = ok && d2h_vec(h, pi, D.pinv, M) && d2h_vec(h, qi, D.qinv, M);
+    ok = ok && d2h_vec(h, cf, D.cflink, 2 * M + 2) && d2h_vec(h, cb, D.cblink, 2 * M + 2) && d2h_vec(h, rf, D.rflink, 2 * M + 2) && d2h_vec(h, rb, D.rblink, 2 * M + 2);
+    ok = ok && hip_ok(h, hipMemcpy(colmax, D.colmax, M * 8, hipMemcpyDeviceToHost), "d2h colmax");
+    if (!ok) return BLU_ERROR_DEVICE;
+    int64_t put = 0;
+    for (size_t j = 0; j < M; j++) {
+        colptr[j] = put;
+        for (int p = 0; p < clen[j]; p++) {
+            colidx[put] = cidx[cbeg[j] + p];
+            colval[put] = cval[cbeg[j] + p];
+            put++;
+        }
+    }
+    colptr[M] = put;
+    put = 0;
+    for (size_t i = 0; i < M; i++) {
+        rowptr[i] = put;
+        for (int p = 0; p < rlen[i]; p++) rowidx[put++] = ridx[rbeg[i] + p];
+    }
+    rowptr[M] = put;
+    for (size_t k = 0; k < M; k++) {
+        pinv[k] = pi[k];
+        qinv[k] = qi[k];
+    }
+    for (size_t k = 0; k < 2 * M + 2; k++) {
+        col_flink[k] = cf[k];
+        col_blink[k] = cb[k];
+        row_flink[k] = rf[k];
+        row_blink[k] = rb[k];
+    }
+    return BLU_OK;
+}
+// same layout as orc_dbg_partial_lu
+extern "C" int blu_hip_dbg_partial_lu(blu_hip *h, int64_t *lptr, int64_t *lidx, double *lval,
+                                      int64_t *uptr, int64_t *uidx, double *uval)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    (void)hipSetDevice(h->device);
+    if (!download_scalars(h)) return BLU_ERROR_DEVICE;
+    const size_t R = (size_t)h->hs.rank;
+    std::vector<int> lb, ub, li, ui;
+    bool ok = d2h_vec(h, lb, h->D.lbeg, R + 1) && d2h_vec(h, ub, h->D.ubeg, R + 1);
+    ok = ok && d2h_vec(h, li, h->D.lidx, (size_t)h->hs.lused) && d2h_vec(h, ui, h->D.uidx, (size_t)h->hs.uused);
+    if (h->hs.lused) ok = ok && hip_ok(h, hipMemcpy(lval, h->D.lval, (size_t)h->hs.lused * 8, hipMemcpyDeviceToHost), "d2h lval");
+    if (h->hs.uused) ok = ok && hip_ok(h, hipMemcpy(uval, h->D.uval, (size_t)h->hs.uused * 8, hipMemcpyDeviceToHost), "d2h uval");
+    if (!ok) return BLU_ERROR_DEVICE;
+    for (size_t k = 0; k <= R; k++) {
+        lptr[k] = lb[k];
+        uptr[k] = ub[k];
+    }
+    for (int k = 0; k < h->hs.lused; k++) lidx[k] = li[k];
+    for (int k = 0; k < h->hs.uused; k++) uidx[k] = ui[k];
+    return BLU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic LP-basis generator, host utility for benchmarks and tests.
+// SplitMix64; draw order documented in DESIGN.md ("Synthetic inputs").
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t sm64_next(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline double sm64_u(uint64_t *s) { return (double)(sm64_next(s) >> 11) * (1.0 / 9007199254740992.0); }
+
+extern "C" int64_t blu_hip_gen_lp_basis(int64_t m, int64_t k, int64_t bw, double tri_frac, double offscale,
+                                        uint64_t seed, uint64_t *colptr, uint64_t *rowidx, double *value)
+{
+    uint64_t s = seed;
+    std::vector<int64_t> gptr((size_t)m + 1), grow, win((size_t)(2 * bw + 2)), P((size_t)m), Q((size_t)m);
+    std::vector<double> gval;
+    grow.reserve((size_t)(m * std::max<int64_t>(k, 1)));
+    gval.reserve((size_t)(m * std::max<int64_t>(k, 1)));
+    const double tri_cut = tri_frac * (double)m;
+    for (int64_t c = 0; c < m; c++) {
+        gptr[(size_t)c] = (int64_t)grow.size();
+        const double u1 = sm64_u(&s), u2 = sm64_u(&s);
+        grow.push_back(c);
+        gval.push_back((u2 < 0.5 ? -1.0 : 1.0) * (1.0 + u1));
+        int64_t nw = 0;
+        const int64_t lo = c - bw < 0 ? 0 : c - bw;
+        if ((double)c < tri_cut) {
+            for (int64_t r = lo; r <= c - 1; r++) win[(size_t)nw++] = r;
+        } else {
+            const int64_t hi = c + bw > m - 1 ? m - 1 : c + bw;
+            for (int64_t r = lo; r <= hi; r++)
+                if (r != c) win[(size_t)nw++] = r;
+        }
+        const int64_t n = std::min<int64_t>(k - 1, nw);
+        for (int64_t t = 0; t < n; t++) {
+            const int64_t r = t + (int64_t)(sm64_u(&s) * (double)(nw - t));
+            std::swap(win[(size_t)t], win[(size_t)r]);
+            const double uv = sm64_u(&s), us = sm64_u(&s);
+            grow.push_back(win[(size_t)t]);
+            gval.push_back((us < 0.5 ? -1.0 : 1.0) * (offscale * (0.1 + 0.9 * uv)));
+        }
+    }
+    gptr[(size_t)m] = (int64_t)grow.size();
+    for (int64_t i = 0; i < m; i++) P[(size_t)i] = i;
+    for (int64_t t = m - 1; t >= 1; t--) std::swap(P[(size_t)t], P[(size_t)(sm64_u(&s) * (double)(t + 1))]);
+    for (int64_t i = 0; i < m; i++) Q[(size_t)i] = i;
+    for (int64_t t = m - 1; t >= 1; t--) std::swap(Q[(size_t)t], Q[(size_t)(sm64_u(&s) * (double)(t + 1))]);
+    std::vector<int64_t> len((size_t)m, 0);
+    for (int64_t c = 0; c < m; c++) len[(size_t)Q[(size_t)c]] = gptr[(size_t)c + 1] - gptr[(size_t)c];
+    colptr[0] = 0;
+    for (int64_t j = 0; j < m; j++) colptr[j + 1] = colptr[j] + (uint64_t)len[(size_t)j];
+    for (int64_t c = 0; c < m; c++) {
+        uint64_t put = colptr[Q[(size_t)c]];
+        for (int64_t pos = gptr[(size_t)c]; pos < gptr[(size_t)c + 1]; pos++) {
+            rowidx[put] = (uint64_t)P[(size_t)grow[(size_t)pos]];
+            value[put] = gval[(size_t)pos];
+            put++;
+        }
+    }
+    return (int64_t)grow.size();
+}

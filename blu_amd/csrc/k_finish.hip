@@ -1,0 +1,273 @@
+// k_finish.hip -- after the pivot loop, one workgroup per matrix:
+//   k_finish  = the result-defining part of build_factors (src/lu/build_factors.rs:179-223, 395-419)
+//               fused with get_factors (src/get_factors.rs:48-180): completes the permutations and
+//               writes the canonical read-out (L: CSC, unit diagonal first, rows sorted; U: CSC,
+//               pivot last, rows sorted; both in pivot order) straight from the stage-ordered L
+//               columns / U rows the pivot loop produced.  The reference's intermediate row-wise L
+//               and column-wise U copies (build_factors.rs:229-384) exist there only to make that
+//               read-out (and the CPU solves) sequential; they are not materialised here.
+//   k_compact = file_compress (src/lu/file.rs:92-135) for the bump-pointer arenas: lines are copied
+//               in index order into a fresh arena with stretch*len+pad room each.
+#include "blu_dev.h"
+
+struct FinishOut {
+    long long *rowperm, *colperm;             // m
+    long long *l_colptr, *l_rowidx;           // m+1, l_nz+m
+    double *l_value;
+    long long *u_colptr, *u_rowidx;           // m+1, u_nz+m
+    double *u_value;
+};
+
+// sort the (key,val) pairs in [b,e) ascending by key; keys distinct.  One thread.
+__device__ __forceinline__ void insertion_sort_pairs(long long *key, double *val, int b, int e)
+{
+    for (int p = b + 1; p < e; p++) {
+        const long long k = key[p];
+        const double v = val[p];
+        int q = p - 1;
+        while (q >= b && key[q] > k) {
+            key[q + 1] = key[q];
+            val[q + 1] = val[q];
+            q--;
+        }
+        key[q + 1] = k;
+        val[q + 1] = v;
+    }
+}
+
+// Workgroup-wide sort of one long segment [b,e) with distinct keys in [0,m): presence bitmap -> rank.
+// flag/rnk: int[m] scratch, stage_k/stage_v: scratch of >= e-b entries.
+__device__ void block_sort_segment(long long *key, double *val, int b, int e, int m, int *flag, int *rnk,
+                                   int *stage_k, double *stage_v, int *sh)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < m; j += nt) flag[j] = 0;
+    __syncthreads();
+    for (int p = b + tid; p < e; p += nt) flag[(int)key[p]] = 1;
+    __syncthreads();
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int j = c0 + tid;
+        const int f = j < m ? flag[j] : 0;
+        int tot;
+        const int ex = block_excl_scan_i(f, sh, &tot);
+        if (j < m) rnk[j] = base + ex;
+        base += tot;
+    }
+    for (int p = b + tid; p < e; p += nt) {
+        const int k = (int)key[p];
+        stage_k[rnk[k]] = k;
+        stage_v[rnk[k]] = val[p];
+    }
+    __syncthreads();
+    for (int p = b + tid; p < e; p += nt) {
+        key[p] = stage_k[p - b];
+        val[p] = stage_v[p - b];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
+{
+    const DevLU &D = Ds[blockIdx.x];
+    const FinishOut &O = Os[blockIdx.x];
+    Scalars *S = D.s;
+    __shared__ int sh[40];
+    __shared__ double shd[40];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = D.m;
+    if (S->status != ST_DONE) return;
+    const int rank = S->rank;
+
+    // ---- complete the permutations: unpivoted rows / columns in index order (build_factors.rs:192-209)
+    for (int pass = 0; pass < 2; pass++) {
+        int *inv = pass == 0 ? D.pinv : D.qinv;
+        int *seq = pass == 0 ? D.prow : D.pcol;
+        int base = rank;
+        for (int c0 = 0; c0 < m; c0 += nt) {
+            const int e = c0 + tid;
+            const int f = (e < m && inv[e] < 0) ? 1 : 0;
+            int tot;
+            const int ex = block_excl_scan_i(f, sh, &tot);
+            if (f) {
+                inv[e] = base + ex;
+                seq[base + ex] = e;
+            }
+            base += tot;
+        }
+        if (base != m && tid == 0) DEV_CHECK(S, false);
+    }
+    __syncthreads();
+    // dependent columns get unit pivots (build_factors.rs:221-223); empty L columns / U rows for them
+    for (int k = rank + tid; k < m; k += nt) {
+        D.colmax[D.pcol[k]] = 1.0;
+        D.lbeg[k + 1] = D.lbeg[rank];
+        D.ubeg[k + 1] = D.ubeg[rank];
+    }
+    for (int k = tid; k < m; k += nt) {
+        O.rowperm[k] = D.prow[k];
+        O.colperm[k] = D.pcol[k];
+    }
+    __syncthreads();
+
+    // ---- L: column k = unit diagonal, then the stage-k column with rows renumbered by pinv and sorted
+    // (get_factors.rs:86-113 scatters the row-wise copy in row order, which sorts each column)
+    const int l_nz = D.lbeg[rank];
+    if (tid == 0) sh[34] = 0;
+    __syncthreads();
+    for (int k = tid; k <= m; k += nt) O.l_colptr[k] = (long long)D.lbeg[k] + k;
+    for (int k = tid; k < m; k += nt) {
+        const int b = D.lbeg[k], e = D.lbeg[k + 1];
+        const int ob = b + k;
+        O.l_rowidx[ob] = k;
+        O.l_value[ob] = 1.0;
+        for (int p = b; p < e; p++) {
+            O.l_rowidx[ob + 1 + (p - b)] = D.pinv[D.lidx[p]];
+            O.l_value[ob + 1 + (p - b)] = D.lval[p];
+        }
+        if (e - b > 48) D.iw2[atomicAdd(&sh[34], 1)] = k;
+        else insertion_sort_pairs(O.l_rowidx, O.l_value, ob + 1, ob + 1 + (e - b));
+    }
+    __syncthreads();
+    {
+        const int nlong = sh[34];
+        __syncthreads();
+        for (int r = 0; r < nlong; r++) {
+            const int k = D.iw2[r];
+            const int b = D.lbeg[k] + k + 1, e = D.lbeg[k + 1] + k + 1;
+            block_sort_segment(O.l_rowidx, O.l_value, b, e, m, D.iw0, D.iw1, D.tnew, D.txrj, sh);
+        }
+    }
+
+    // ---- U: column k collects the entries (stage k', column pcol[k]) of all U rows, ascending k'
+    // (get_factors.rs:136-167); entries in columns that never became pivotal are dropped
+    // (build_factors.rs:318-337, `qinv[j] < rank`)
+    for (int k = tid; k < m; k += nt) D.iw0[k] = 0;
+    __syncthreads();
+    for (int k = tid; k < rank; k += nt)
+        for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
+            const int c = D.qinv[D.uidx[p]];
+            if (c < rank) atomicAdd(&D.iw0[c], 1);
+        }
+    __syncthreads();
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int k = c0 + tid;
+        const int cnt = k < m ? D.iw0[k] + 1 : 0;
+        int tot;
+        const int ex = block_excl_scan_i(cnt, sh, &tot);
+        if (k < m) {
+            O.u_colptr[k] = base + ex;
+            D.iw1[k] = base + ex; // fill cursor
+        }
+        base += tot;
+    }
+    const int u_tot = base; // u_nz + m
+    if (tid == 0) {
+        O.u_colptr[m] = u_tot;
+        sh[34] = 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < rank; k += nt)
+        for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
+            const int c = D.qinv[D.uidx[p]];
+            if (c < rank) {
+                const int pos = atomicAdd(&D.iw1[c], 1);
+                O.u_rowidx[pos] = k;
+                O.u_value[pos] = D.uval[p];
+            }
+        }
+    __syncthreads();
+    double pmin = INFINITY, pmax = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        const int b = (int)O.u_colptr[k], e = b + D.iw0[k];
+        const double piv = D.colmax[D.pcol[k]];
+        O.u_rowidx[e] = k; // pivot last
+        O.u_value[e] = piv;
+        pmin = fmin(pmin, fabs(piv));
+        pmax = fmax(pmax, fabs(piv));
+        if (e - b > 48) D.iw2[atomicAdd(&sh[34], 1)] = k;
+        else insertion_sort_pairs(O.u_rowidx, O.u_value, b, e);
+    }
+    __syncthreads();
+    {
+        const int nlong = sh[34];
+        __syncthreads();
+        for (int r = 0; r < nlong; r++) {
+            const int k = D.iw2[r];
+            const int b = (int)O.u_colptr[k];
+            block_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], m, D.iw1, D.tnewr, D.tnew, D.txrj, sh);
+        }
+    }
+    // min / max pivot (build_factors.rs:403-419)
+    pmin = wave_max_d(-pmin); // max of negatives = -min
+    pmax = wave_max_d(pmax);
+    if (lane_id() == 0) {
+        shd[wave_id()] = pmin;
+        shd[16 + wave_id()] = pmax;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = shd[0], b = shd[16];
+        for (int w = 1; w < num_waves(); w++) {
+            a = a > shd[w] ? a : shd[w];
+            b = b > shd[16 + w] ? b : shd[16 + w];
+        }
+        S->min_pivot = -a;
+        S->max_pivot = b;
+        S->l_nz = l_nz;
+        S->u_nz = u_tot - m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compact: copy every line of one file into a new arena (which = 0 column file, 1 row file)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_compact(DevLU *Ds, int which, int *const *new_idx, double *const *new_val,
+                                                  const int *new_cap)
+{
+    const DevLU &D = Ds[blockIdx.x];
+    Scalars *S = D.s;
+    __shared__ int sh[40];
+    const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), nw = num_waves(), lane = lane_id();
+    const int m = D.m;
+    int *beg = which ? D.rbeg : D.cbeg, *len = which ? D.rlen : D.clen, *cap = which ? D.rcap : D.ccap;
+    const int *old_idx = which ? D.ridx : D.cidx;
+    int *nidx = new_idx[blockIdx.x];
+    double *nval = which ? nullptr : new_val[blockIdx.x];
+    // new offsets; lines that hold nothing get no room (they are dead: pivoted or emptied)
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int e = c0 + tid;
+        const int l = e < m ? len[e] : 0;
+        const int c = l > 0 ? l + stretch_of(D.stretch, l) + D.pad : 0;
+        int tot;
+        const int ex = block_excl_scan_i(c, sh, &tot);
+        if (e < m) {
+            D.iw0[e] = base + ex;
+            D.iw1[e] = c;
+        }
+        base += tot;
+    }
+    if (base > new_cap[blockIdx.x]) {
+        if (tid == 0) DEV_CHECK(S, false);
+        return;
+    }
+    __syncthreads();
+    for (int e = w; e < m; e += nw) {
+        const int l = len[e], ob = beg[e], nb = D.iw0[e];
+        for (int p = lane; p < l; p += 64) {
+            nidx[nb + p] = old_idx[ob + p];
+            if (!which) nval[nb + p] = D.cval[ob + p];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += nt) {
+        beg[e] = D.iw0[e];
+        cap[e] = D.iw1[e];
+    }
+    if (tid == 0) {
+        if (which) S->rused = base; else S->cused = base;
+        S->ngarbage++;
+    }
+}

@@ -1,0 +1,515 @@
+// k_prep.hip -- O(nnz) phases in front of the pivot loop, one workgroup per matrix.
+//
+//   k_prep   = singletons()  (src/lu/singletons.rs:81-264): validate B, build the row-wise copy,
+//              peel singleton columns/rows (without cascade: reference defect D1)
+//   k_setup  = setup_bump()  (src/lu/setup_bump.rs:55-264): column file, row file, count lists
+//
+// Both are restated data-parallel: the reference's sequential loops are replaced by
+// count / scan / ordered-fill passes that produce the same order of entries and the same
+// order of elements in the count lists (ascending index inside a list, list.rs:65-70).
+#include "blu_dev.h"
+
+// ---------------------------------------------------------------------------------------------
+// ordered tail-append of elements 0..n-1 (ascending) into count lists by key, ONE wave.
+// keys[e] < 0 : element is not inserted.  Equivalent to `for e in 0..n { list_add(e, keys[e]) }`
+// (list.rs:54-77).  Returns the minimum key > 0 seen (or big).
+// ---------------------------------------------------------------------------------------------
+__device__ int wave_list_build(int *flink, int *blink, int n, const int *keys, int big)
+{
+    const int lane = lane_id();
+    int minkey = big;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int e = c0 + lane;
+        int key = e < n ? keys[e] : -1;
+        bool act = key >= 0;
+        if (act && key > 0) minkey = min(minkey, key);
+        unsigned long long active = __ballot(act);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int k = __shfl(key, leader);
+            const unsigned long long grp = __ballot(act && key == k);
+            const int tail = blink[n + k];
+            if (act && key == k) {
+                const unsigned long long below = grp & lanes_below(lane);
+                const unsigned long long above = grp & ~((2ull << lane) - 1ull);
+                const int prevl = below ? 63 - __clzll((long long)below) : -1;
+                const int nextl = above ? __ffsll((long long)above) - 1 : -1;
+                blink[e] = prevl >= 0 ? c0 + prevl : tail;
+                flink[e] = nextl >= 0 ? c0 + nextl : n + k;
+                if (prevl < 0) flink[tail] = e;
+                if (nextl < 0) blink[n + k] = e;
+                act = false;
+            }
+            active &= ~grp;
+        }
+        wave_mem_sync(); // the next chunk reads blink[n+k] written here
+    }
+    return wave_min_i(minkey);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prep
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
+{
+    const DevLU &D = Ds[blockIdx.x];
+    Scalars *S = D.s;
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = D.m;
+    if (S->status != ST_RUNNING) return;
+
+    // ---- check pointers, count nnz(B), column pointers of the packed copy (singletons.rs:119-133)
+    int bad = 0;
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int j = c0 + tid;
+        int len = 0;
+        if (j < m) {
+            const unsigned long long b = D.b_begin[j], e = D.b_end[j];
+            if (e < b) bad = 1;
+            else if (e - b > 0x7fffffffull || e > (unsigned long long)D.b_i_len) bad = 1; // outside the caller's b_i/b_x
+            else len = (int)(e - b);
+        }
+        int tot;
+        int ex = block_excl_scan_i(len, sh, &tot);
+        if (j < m) D.bc_ptr[j] = base + ex;
+        if ((long long)base + tot > 0x7fffffffLL) bad = 1;
+        base += tot;
+    }
+    bad = block_or_i(bad, sh);
+    if (bad) {
+        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        return;
+    }
+    const int b_nz = base;
+    if (tid == 0) {
+        D.bc_ptr[m] = b_nz;
+        S->matrix_nz = b_nz;
+    }
+    if (b_nz > D.nzcap) { // host sized the packed copies too small (overlapping columns): ask for more
+        if (tid == 0) {
+            S->need = b_nz;
+            set_error(S, ST_NEED_CW, __LINE__);
+        }
+        return;
+    }
+    for (int i = tid; i < m; i += nt) D.iw0[i] = 0;
+    __syncthreads();
+
+    // ---- count nz per row, check indices, pack columns (singletons.rs:152-173)
+    for (int j = tid; j < m; j += nt) {
+        const unsigned long long b = D.b_begin[j], e = D.b_end[j];
+        int put = D.bc_ptr[j];
+        for (unsigned long long pos = b; pos < e; pos++) {
+            const unsigned long long i = D.b_i[pos];
+            if (i >= (unsigned long long)m) {
+                bad = 1;
+            } else {
+                atomicAdd(&D.iw0[(int)i], 1);
+                D.bc_idx[put] = (int)i;
+                D.bc_val[put] = D.b_x[pos];
+            }
+            put++;
+        }
+    }
+    bad = block_or_i(bad, sh);
+    if (bad) {
+        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        return;
+    }
+
+    // ---- row pointers (singletons.rs:176-183)
+    base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int i = c0 + tid;
+        const int cnt = i < m ? D.iw0[i] : 0;
+        int tot;
+        int ex = block_excl_scan_i(cnt, sh, &tot);
+        if (i < m) {
+            D.bt_ptr[i] = base + ex;
+            D.iw1[i] = base + ex; // fill cursor
+        }
+        base += tot;
+    }
+    if (tid == 0) D.bt_ptr[m] = base;
+    __syncthreads();
+
+    // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
+    // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
+    for (int j = tid; j < m; j += nt) {
+        for (int pos = D.bc_ptr[j]; pos < D.bc_ptr[j + 1]; pos++) {
+            const int i = D.bc_idx[pos];
+            const int p = atomicAdd(&D.iw1[i], 1);
+            D.bt_idx[p] = j;
+            D.bt_val[p] = D.bc_val[pos];
+        }
+    }
+    __syncthreads();
+    // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the workgroup
+    if (tid == 0) sh[34] = 0; // number of long rows
+    __syncthreads();
+    for (int i = tid; i < m; i += nt) {
+        const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
+        if (e - b > 48) {
+            const int k = atomicAdd(&sh[34], 1);
+            D.iw2[k] = i; // list of long rows (order irrelevant)
+            continue;
+        }
+        for (int p = b + 1; p < e; p++) {
+            const int kj = D.bt_idx[p];
+            const double kv = D.bt_val[p];
+            int q = p - 1;
+            while (q >= b && D.bt_idx[q] > kj) {
+                D.bt_idx[q + 1] = D.bt_idx[q];
+                D.bt_val[q + 1] = D.bt_val[q];
+                q--;
+            }
+            D.bt_idx[q + 1] = kj;
+            D.bt_val[q + 1] = kv;
+        }
+        for (int p = b + 1; p < e; p++)
+            if (D.bt_idx[p] == D.bt_idx[p - 1]) bad = 1; // duplicate (singletons.rs:195-197)
+    }
+    __syncthreads();
+    const int nlong = sh[34];
+    __syncthreads();
+    for (int r = 0; r < nlong; r++) {
+        const int i = D.iw2[r];
+        const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
+        // bitmap of columns present in row i -> rank of each column -> ordered rewrite
+        for (int j = tid; j < m; j += nt) D.iw0[j] = 0;
+        __syncthreads();
+        for (int p = b + tid; p < e; p += nt)
+            if (atomicAdd(&D.iw0[D.bt_idx[p]], 1) != 0) bad = 1; // duplicate
+        __syncthreads();
+        int rb = 0;
+        for (int c0 = 0; c0 < m; c0 += nt) {
+            const int j = c0 + tid;
+            const int f = j < m ? (D.iw0[j] ? 1 : 0) : 0;
+            int tot;
+            int ex = block_excl_scan_i(f, sh, &tot);
+            if (j < m) D.iw1[j] = rb + ex; // rank of column j inside the row
+            rb += tot;
+        }
+        // stage (idx,val) in the column arena's scratch-free tail: use tnew/txrj (m entries each)
+        for (int p = b + tid; p < e; p += nt) {
+            const int j = D.bt_idx[p];
+            const int rk = D.iw1[j];
+            D.tnew[rk] = j;
+            D.txrj[rk] = D.bt_val[p];
+        }
+        __syncthreads();
+        for (int p = b + tid; p < e; p += nt) {
+            D.bt_idx[p] = D.tnew[p - b];
+            D.bt_val[p] = D.txrj[p - b];
+        }
+        __syncthreads();
+    }
+    bad = block_or_i(bad, sh);
+    if (bad) {
+        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        return;
+    }
+
+    // ---- pivot singletons (singletons.rs:203-258), no cascade (D1)
+    for (int i = tid; i < m; i += nt) {
+        D.pinv[i] = -1;
+        D.qinv[i] = -1;
+    }
+    if (tid == 0) {
+        D.lbeg[0] = 0;
+        D.ubeg[0] = 0;
+    }
+    __syncthreads();
+    int rank = 0, lused = 0, uused = 0;
+    const double abstol = D.abstol;
+    for (int phase = 0; phase < 2; phase++) {
+        const bool cols = (D.nzbias >= 0) ? (phase == 0) : (phase == 1);
+        // winner table: per row the smallest singleton column with an acceptable pivot (or per column the
+        // smallest singleton row).  In queue order (ascending index, singletons.rs:318-329) the first
+        // acceptable one eliminates the line and empties the others (:337-339, :352-355).
+        for (int i = tid; i < m; i += nt) D.iw0[i] = 0x7fffffff;
+        __syncthreads();
+        for (int e = tid; e < m; e += nt) {
+            if (cols) {
+                const int j = e;
+                if (D.qinv[j] < 0 && D.bc_ptr[j + 1] - D.bc_ptr[j] == 1) {
+                    const int i = D.bc_idx[D.bc_ptr[j]];
+                    const double piv = D.bc_val[D.bc_ptr[j]];
+                    DEV_CHECK(S, D.pinv[i] < 0);
+                    if (!(piv == 0.0 || fabs(piv) < abstol)) atomicMin(&D.iw0[i], j);
+                }
+            } else {
+                const int i = e;
+                if (D.pinv[i] < 0 && D.bt_ptr[i + 1] - D.bt_ptr[i] == 1) {
+                    const int j = D.bt_idx[D.bt_ptr[i]];
+                    const double piv = D.bt_val[D.bt_ptr[i]];
+                    DEV_CHECK(S, D.qinv[j] < 0);
+                    if (!(piv == 0.0 || fabs(piv) < abstol)) atomicMin(&D.iw0[j], i);
+                }
+            }
+        }
+        __syncthreads();
+        // ranks of the winners in ascending index
+        int nwin = 0;
+        for (int c0 = 0; c0 < m; c0 += nt) {
+            const int e = c0 + tid;
+            int win = 0, other = -1;
+            double piv = 0.0;
+            if (e < m) {
+                if (cols) {
+                    if (D.qinv[e] < 0 && D.bc_ptr[e + 1] - D.bc_ptr[e] == 1) {
+                        other = D.bc_idx[D.bc_ptr[e]];
+                        piv = D.bc_val[D.bc_ptr[e]];
+                        win = (D.iw0[other] == e);
+                    }
+                } else {
+                    if (D.pinv[e] < 0 && D.bt_ptr[e + 1] - D.bt_ptr[e] == 1) {
+                        other = D.bt_idx[D.bt_ptr[e]];
+                        piv = D.bt_val[D.bt_ptr[e]];
+                        win = (D.iw0[other] == e);
+                    }
+                }
+            }
+            int tot;
+            int ex = block_excl_scan_i(win, sh, &tot);
+            if (win) {
+                const int r = rank + nwin + ex;
+                const int i = cols ? other : e, j = cols ? e : other;
+                D.prow[r] = i;
+                D.pcol[r] = j;
+                D.iw1[r] = e; // winners in rank order
+                D.colmax[j] = piv;
+            }
+            nwin += tot;
+        }
+        __syncthreads();
+        for (int r = rank + tid; r < rank + nwin; r += nt) {
+            D.pinv[D.prow[r]] = r;
+            D.qinv[D.pcol[r]] = r;
+        }
+        __syncthreads();
+        // factor entries of the new stages, in stage order
+        int put0 = cols ? uused : lused;
+        for (int c0 = 0; c0 < nwin; c0 += nt) {
+            const int r = rank + c0 + tid;
+            int cnt = 0;
+            if (r < rank + nwin) {
+                if (cols) { // U row = entries of row i in still-active columns (singletons.rs:360-377)
+                    const int i = D.prow[r];
+                    for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) cnt += (D.qinv[D.bt_idx[p]] < 0);
+                } else { // L column = entries of column j in still-active rows, divided by the pivot (:469-487)
+                    const int j = D.pcol[r];
+                    for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) cnt += (D.pinv[D.bc_idx[p]] < 0);
+                }
+            }
+            int tot;
+            int ex = block_excl_scan_i(cnt, sh, &tot);
+            if (r < rank + nwin) {
+                int put = put0 + ex;
+                const bool fits = cols ? (put0 + tot <= D.ucap) : (put0 + tot <= D.lcap);
+                if (cols) {
+                    D.ubeg[r + 1] = put + cnt;
+                    D.lbeg[r + 1] = lused;
+                    if (fits) {
+                        const int i = D.prow[r];
+                        for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) {
+                            const int j2 = D.bt_idx[p];
+                            if (D.qinv[j2] < 0) {
+                                D.uidx[put] = j2;
+                                D.uval[put] = D.bt_val[p];
+                                put++;
+                            }
+                        }
+                    }
+                } else {
+                    D.lbeg[r + 1] = put + cnt;
+                    D.ubeg[r + 1] = uused;
+                    if (fits) {
+                        const int j = D.pcol[r];
+                        const double piv = D.colmax[j];
+                        for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
+                            const int i2 = D.bc_idx[p];
+                            if (D.pinv[i2] < 0) {
+                                D.lidx[put] = i2;
+                                D.lval[put] = D.bc_val[p] / piv;
+                                put++;
+                            }
+                        }
+                    }
+                }
+            }
+            put0 += tot;
+        }
+        if (cols) uused = put0; else lused = put0;
+        rank += nwin;
+        __syncthreads();
+    }
+    // singletons.rs:135-150 guarantees l_mem, u_mem >= nnz(B) up front; here L/U are sized by the host
+    if (uused > D.ucap || lused > D.lcap) {
+        if (tid == 0) {
+            S->need = max(uused, lused);
+            set_error(S, uused > D.ucap ? ST_NEED_U : ST_NEED_L, __LINE__);
+        }
+        return;
+    }
+    if (tid == 0) {
+        S->rank = rank;
+        S->rank0 = rank;
+        S->lused = lused;
+        S->uused = uused;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_setup = setup_bump (setup_bump.rs:55-264)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
+{
+    const DevLU &D = Ds[blockIdx.x];
+    Scalars *S = D.s;
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = D.m;
+    if (S->status != ST_RUNNING) return;
+    const int rank = S->rank;
+    const double abstol = D.abstol, stretch = D.stretch;
+    const int pad = D.pad;
+
+    // ---- columns: count, maximum, capacity (setup_bump.rs:131-186).  iw0[j] = list key:
+    //      -2 column not active, 0 dropped (cmx == 0 or < abstol), else cnz
+    int base = 0;
+    long long dropped_nz = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int j = c0 + tid;
+        int cap = 0, cnz = 0, key = -2;
+        double cmx = 0.0;
+        if (j < m && D.qinv[j] < 0) {
+            for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
+                if (D.pinv[D.bc_idx[p]] >= 0) continue;
+                cmx = fmax(cmx, fabs(D.bc_val[p]));
+                cnz++;
+            }
+            if (cmx == 0.0 || cmx < abstol) {
+                key = 0;
+                dropped_nz += cnz;
+                cmx = 0.0;
+                cnz = 0;
+            } else {
+                key = cnz;
+                cap = cnz + stretch_of(stretch, cnz) + pad;
+            }
+        }
+        int tot;
+        int ex = block_excl_scan_i(cap, sh, &tot);
+        if (j < m) {
+            D.iw0[j] = key;
+            D.cbeg[j] = key > 0 ? base + ex : 0;
+            D.clen[j] = key > 0 ? cnz : 0;
+            D.ccap[j] = cap;
+            if (key >= 0) D.colmax[j] = cmx;
+        }
+        if ((long long)base + tot > (long long)D.carena_cap) {
+            if (tid == 0) {
+                S->need = base + tot;
+                set_error(S, ST_NEED_CW, __LINE__);
+            }
+            return; // uniform: base/tot are workgroup-uniform
+        }
+        base += tot;
+    }
+    const int cused = base;
+    dropped_nz = block_sum_ll(dropped_nz, shl);
+    __syncthreads();
+    for (int j = tid; j < m; j += nt) {
+        if (D.iw0[j] <= 0) continue;
+        int put = D.cbeg[j];
+        for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
+            const int i = D.bc_idx[p];
+            if (D.pinv[i] >= 0) continue;
+            D.cidx[put] = i;
+            D.cval[put] = D.bc_val[p];
+            put++;
+        }
+    }
+
+    // ---- rows: pattern of the copied columns in ascending column order (setup_bump.rs:188-224)
+    base = 0;
+    for (int c0 = 0; c0 < m; c0 += nt) {
+        const int i = c0 + tid;
+        int cap = 0, rnz = 0, key = -2;
+        if (i < m && D.pinv[i] < 0) {
+            for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) rnz += (D.iw0[D.bt_idx[p]] > 0);
+            key = rnz;
+            cap = rnz + stretch_of(stretch, rnz) + pad;
+        }
+        int tot;
+        int ex = block_excl_scan_i(cap, sh, &tot);
+        if (i < m) {
+            D.iw1[i] = key;
+            D.rbeg[i] = key >= 0 ? base + ex : 0;
+            D.rlen[i] = key >= 0 ? rnz : 0;
+            D.rcap[i] = cap;
+        }
+        if ((long long)base + tot > (long long)D.rarena_cap) {
+            if (tid == 0) {
+                S->need = base + tot;
+                set_error(S, ST_NEED_RW, __LINE__);
+            }
+            return;
+        }
+        base += tot;
+    }
+    const int rused = base;
+    __syncthreads();
+    for (int i = tid; i < m; i += nt) {
+        if (D.iw1[i] < 0) continue;
+        int put = D.rbeg[i];
+        for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) {
+            const int j = D.bt_idx[p];
+            if (D.iw0[j] > 0) D.ridx[put++] = j;
+        }
+    }
+
+    // ---- count lists (setup_bump.rs:124-130, 188-194): list_init, then list_add in ascending index
+    for (int e = tid; e < 2 * m + 2; e += nt) {
+        D.cflink[e] = e;
+        D.cblink[e] = e;
+        D.rflink[e] = e;
+        D.rblink[e] = e;
+    }
+    for (int e = tid; e < m; e += nt) {
+        D.rowmark[e] = 0;
+        D.colmark[e] = 0;
+    }
+    {
+        const long long ng = (long long)num_waves() * (m + 1);
+        for (long long e = tid; e < ng; e += nt) D.gwork[e] = 0.0;
+    }
+    __syncthreads();
+    const int w = wave_id();
+    if (w == 0) {
+        int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2);
+        if (lane_id() == 0) S->min_colnz = mn; // list_init sets min_list = max(1, nlist) = m + 2 (list.rs:48-50)
+    } else if (w == 1 || num_waves() == 1) {
+        int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2);
+        if (lane_id() == 0) S->min_rownz = mn;
+    }
+    if (num_waves() == 1 && w == 0) {
+        int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2);
+        if (lane_id() == 0) S->min_rownz = mn;
+    }
+    if (tid == 0) {
+        const long long l_nz = S->lused, u_nz = S->uused;
+        S->bump_nz = S->matrix_nz - l_nz - u_nz - rank - dropped_nz; // setup_bump.rs:89, :155
+        S->bump_size = m - rank;
+        S->cused = cused;
+        S->rused = rused;
+        S->pivot_row = -1;
+        S->pivot_col = -1;
+        S->rankdef = 0;
+    }
+}
