@@ -26,7 +26,7 @@ struct Sm {
     int exit_code, need;
     int flag_small;
     int other_row, where, ncancel, nfill;
-    int stop_at;
+    int stop_at, need_search;
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
     long long kinds[6];
@@ -1144,12 +1144,15 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             if (S->status != ST_RUNNING) sm->exit_code = S->status;
             else if (sm->rank + sm->rankdef >= m) sm->exit_code = ST_DONE;
             else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) sm->exit_code = ST_STOPPED;
+            sm->need_search = sm->pc < 0;
         }
         __syncthreads();
         if (sm->exit_code) break;
 
         // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
-        if (sm->pc < 0) {
+        // `need_search` is decided by thread 0 before the barrier above: sm->pc itself is rewritten by
+        // the searching wave, so testing it here would race with slower waves.
+        if (sm->need_search) {
             if (w == 0) {
                 if (D.search_rows == 0) markowitz_wave(D, sm);
                 else if (lane == 0) markowitz_serial(D, sm);
@@ -1166,6 +1169,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             break;
         }
         if (pr < 0) { // eliminate empty column without choosing a pivot (factorize_bump.rs:24-33)
+            __syncthreads(); // every thread has read sm->pr / sm->pc before thread 0 rewrites them
             if (tid == 0) {
                 list_remove1(D.cflink, D.cblink, pc);
                 sm->pc = -1;

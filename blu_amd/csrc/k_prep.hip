@@ -481,13 +481,12 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
         D.rflink[e] = e;
         D.rblink[e] = e;
     }
+    // scratch that the pivot loop expects all-zero (freshly hipMalloc'ed memory is NOT zero when the
+    // allocator recycles a block); gwork is zeroed by the host at allocation and kept zero by its users
     for (int e = tid; e < m; e += nt) {
         D.rowmark[e] = 0;
         D.colmark[e] = 0;
-    }
-    {
-        const long long ng = (long long)num_waves() * (m + 1);
-        for (long long e = tid; e < ng; e += nt) D.gwork[e] = 0.0;
+        D.iw2[e] = 0;
     }
     __syncthreads();
     const int w = wave_id();

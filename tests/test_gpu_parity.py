@@ -1,0 +1,268 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libblu_hip.so (include/blu_hip.h), against the CPU oracle and the committed golden fixtures.
+
+Bar (BASELINE.json north_star): permutations and all integer arrays bit-exact; L/U values within
+1e-12 relative (in practice they are bit-identical: same IEEE operations in the same order).
+"""
+import numpy as np
+import pytest
+
+from blu_amd import keys as K
+from blu_amd.matrices import CONFIGS, simple_rs
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def blu():
+    import blu_amd
+    if blu_amd.lib().blu_hip_device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return blu_amd
+
+
+def _both(blu, oracle, cp, ri, v, params=None, cap=None, block=None, fix_d3=False):
+    m = len(cp) - 1
+    g = blu.BLU(m, len(ri))
+    o = oracle.OracleBLU(m, cap if cap else 32 * len(ri) + 1024)
+    if fix_d3:
+        o.set_fix_d3(True)
+    for k, val in (params or {}).items():
+        g.set_param(k, val)
+        o.set_param(k, val)
+    if block:
+        g.dbg_set_block(block)
+    sg = g.factorize(cp[:-1], cp[1:], ri, v)
+    so = o.factorize(cp[:-1], cp[1:], ri, v)
+    return g, o, sg, so
+
+
+def _assert_parity(g, o, sg, so, cp, ri, v):
+    assert sg == so
+    fg, fo = g.get_factors(), o.get_factors()
+    util.assert_same_factors(fg, fo)
+    for c in util.COUNTERS:
+        assert int(g.stat(getattr(K, "STAT_" + c))) == int(o.stat(getattr(K, "STAT_" + c))), c
+    for c in ("MIN_PIVOT", "MAX_PIVOT"):
+        a, b = g.stat(getattr(K, "STAT_" + c)), o.stat(getattr(K, "STAT_" + c))
+        assert abs(a - b) <= util.RTOL * abs(b), c
+    return fg
+
+
+def test_simple_rs(blu, oracle):
+    cp, ri, v, b, x = simple_rs()
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, cap=len(ri))
+    assert sg == K.OK
+    fg = _assert_parity(g, o, sg, so, cp, ri, v)
+    assert fg["rowperm"][:2].tolist() == [5, 2] and fg["colperm"][:2].tolist() == [5, 2]
+    np.testing.assert_allclose(g.solve_dense(b, "N"), x, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g.solve_dense(b, "T"), x, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("path", util.golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_fixtures(blu, path):
+    """Committed fixtures (tests/golden/, made by the oracle): no oracle call on this path."""
+    gold = np.load(path)
+    m = len(gold["colptr"]) - 1
+    g = blu.BLU(m, len(gold["rowidx"]))
+    st = g.factorize(gold["colptr"][:-1], gold["colptr"][1:], gold["rowidx"], gold["values"])
+    assert st == int(gold["status"])
+    f = g.get_factors()
+    util.assert_same_factors(f, gold)
+    for c in util.COUNTERS:
+        assert int(g.stat(getattr(K, "STAT_" + c))) == int(gold["stat_" + c]), c
+    util.check_factors(gold["colptr"], gold["rowidx"], gold["values"], f)
+
+
+@pytest.mark.parametrize("m,k,bw,tri,offs,seed", [(300, 5, 4, 0.5, 0.3, 1), (800, 8, 8, 0.3, 0.5, 2), (1500, 10, 9, 0.5, 0.3, 5)])
+@pytest.mark.parametrize("nzbias,search_rows", [(1, 0), (-1, 0), (1, 1), (-1, 1)])
+@pytest.mark.parametrize("block", [1024, 256, 64])
+def test_parameters_and_workgroup_sizes(blu, oracle, m, k, bw, tri, offs, seed, nzbias, search_rows, block):
+    cp, ri, v = oracle.gen_lp_basis(m, k, bw, tri, seed, offs)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, {K.PARAM_NZBIAS: nzbias, K.PARAM_SEARCH_ROWS: search_rows}, block=block)
+    assert sg == K.OK
+    _assert_parity(g, o, sg, so, cp, ri, v)
+
+
+@pytest.mark.parametrize("params", [
+    {K.PARAM_RELTOL: 0.5}, {K.PARAM_RELTOL: 1.0}, {K.PARAM_MAXSEARCH: 1}, {K.PARAM_MAXSEARCH: 8},
+    {K.PARAM_DROPTOL: 1e-8}, {K.PARAM_ABSTOL: 1e-3}, {K.PARAM_PAD: 0, K.PARAM_STRETCH: 0.0},
+], ids=lambda p: ",".join("%d=%g" % kv for kv in p.items()))
+def test_tolerances_and_search_depth(blu, oracle, params):
+    cp, ri, v = oracle.gen_lp_basis(1200, 8, 10, 0.4, 9, 0.6)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, params, fix_d3=True)
+    _assert_parity(g, o, sg, so, cp, ri, v)
+
+
+def test_dense_matrix_pivot_any(blu, oracle):
+    """Pivot columns with more than 64 off-diagonals take the pivot_any path (pivot.rs:114)."""
+    rng = np.random.default_rng(3)
+    m = 150
+    A = rng.standard_normal((m, m)) + 5 * np.eye(m)
+    cp = np.arange(0, m * m + 1, m, dtype=np.uint64)
+    ri = np.tile(np.arange(m, dtype=np.uint64), m)
+    v = A.T.reshape(-1).copy()
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    assert sg == K.OK
+    _assert_parity(g, o, sg, so, cp, ri, v)
+    assert g.stat(55) > 0  # pivot_any executed
+    xs = rng.standard_normal(m)
+    np.testing.assert_allclose(g.solve_dense(A @ xs), xs, rtol=1e-8, atol=1e-9)
+
+
+def test_long_rows_and_columns(blu, oracle):
+    """Arrow matrix: one dense row and one dense column (long lines: multi-chunk paths, bitmap sorts)."""
+    m = 700
+    rng = np.random.default_rng(5)
+    cols = []
+    for j in range(m):
+        e = {j: 4.0 + rng.random()}
+        e[m - 1] = rng.random() + 0.1  # dense last row
+        if j == m - 1:
+            for i in range(m):
+                e[i] = rng.random() + 0.1 if i != j else 10.0
+        cols.append(sorted(e.items(), key=lambda t: (t[0] * 7919) % m))  # unsorted rows
+    cp = np.zeros(m + 1, np.uint64)
+    ri, v = [], []
+    for j, c in enumerate(cols):
+        for i, x in c:
+            ri.append(i); v.append(x)
+        cp[j + 1] = len(ri)
+    ri, v = np.array(ri, np.uint64), np.array(v)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    assert sg == K.OK
+    _assert_parity(g, o, sg, so, cp, ri, v)
+
+
+def test_singular_matrices(blu, oracle):
+    m = 6
+    cols = {0: [(0, 2.0), (1, 1.0)], 1: [(1, 3.0)], 2: [(2, 1.5), (0, 0.5)], 3: [], 4: [(4, 1e-18)], 5: [(5, 4.0), (2, 1.0)]}
+    cp, ri, v = [0], [], []
+    for j in range(m):
+        for (i, x) in cols[j]:
+            ri.append(i); v.append(x)
+        cp.append(len(ri))
+    cp, ri, v = np.array(cp, np.uint64), np.array(ri, np.uint64), np.array(v)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
+    assert sg == K.WARNING_SINGULAR_MATRIX
+    f = _assert_parity(g, o, sg, so, cp, ri, v)
+    util.check_factors(cp, ri, v, f, rank=4)
+    # larger: a well-conditioned basis with some columns zeroed / made tiny / duplicated structure removed
+    cp, ri, v = oracle.gen_lp_basis(900, 7, 8, 0.5, 21, 0.4)
+    v = v.copy()
+    for j in (3, 77, 500, 899):
+        v[int(cp[j]):int(cp[j + 1])] *= 1e-17
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
+    assert sg == K.WARNING_SINGULAR_MATRIX
+    f = _assert_parity(g, o, sg, so, cp, ri, v)
+    assert int(g.stat(K.STAT_RANK)) == 896
+
+
+def test_columns_that_sink_below_abstol_are_removed(blu, oracle):
+    """remove_col path (pivot.rs:99-105, 1333-1381): make two columns identical so that elimination
+    cancels one of them exactly."""
+    cp, ri, v = oracle.gen_lp_basis(400, 6, 6, 0.0, 13, 0.5)
+    cp = cp.copy(); ri = ri.copy(); v = v.copy()
+    # make column 11 a copy of column 10's pattern and values (rank deficiency discovered mid-bump)
+    a, b = int(cp[10]), int(cp[11])
+    c, d = int(cp[11]), int(cp[12])
+    n = min(b - a, d - c)
+    cols = [(ri[int(cp[j]):int(cp[j + 1])].copy(), v[int(cp[j]):int(cp[j + 1])].copy()) for j in range(400)]
+    cols[11] = (cols[10][0].copy(), cols[10][1].copy())
+    ncp = np.zeros(401, np.uint64)
+    nri, nv = [], []
+    for j in range(400):
+        nri.extend(cols[j][0].tolist()); nv.extend(cols[j][1].tolist())
+        ncp[j + 1] = len(nri)
+    nri, nv = np.array(nri, np.uint64), np.array(nv)
+    g, o, sg, so = _both(blu, oracle, ncp, nri, nv, fix_d3=True)
+    assert sg == K.WARNING_SINGULAR_MATRIX
+    _assert_parity(g, o, sg, so, ncp, nri, nv)
+
+
+def test_invalid_arguments_and_calls(blu):
+    cp = np.array([0, 2, 4, 5], np.uint64)
+    ri = np.array([0, 1, 1, 2, 2], np.uint64)
+    v = np.ones(5)
+    g = blu.BLU(3, 5)
+    with pytest.raises(blu.BluError):  # get_factors before factorize: ErrorInvalidCall
+        g.get_factors()
+    with pytest.raises(blu.BluError):
+        g.solve_dense(np.ones(3))
+    assert g.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    bad = ri.copy(); bad[1] = 3
+    assert g.factorize(cp[:-1], cp[1:], bad, v) == K.ERROR_INVALID_ARGUMENT
+    with pytest.raises(blu.BluError):  # a failed factorize invalidates the old factors (lu.reset)
+        g.get_factors()
+    dup = ri.copy(); dup[1] = 0
+    assert g.factorize(cp[:-1], cp[1:], dup, v) == K.ERROR_INVALID_ARGUMENT
+    bb = cp[:-1].copy(); be = cp[1:].copy(); bb[0] = 2; be[0] = 0
+    assert g.factorize(bb, be, ri, v) == K.ERROR_INVALID_ARGUMENT
+    assert g.factorize(cp[:-1], cp[1:], ri, v) == K.OK  # handle stays usable
+    assert blu.lib().blu_hip_new(-1, 1, 0) is None
+    assert blu.lib().blu_hip_new(3, 3, 99) is None
+
+
+def test_refactorize_same_handle_and_tiny(blu, oracle):
+    g = blu.BLU(1, 1)
+    assert g.factorize(np.array([0], np.uint64), np.array([1], np.uint64), np.array([0], np.uint64), np.array([2.5])) == K.OK
+    assert g.solve_dense(np.array([5.0]))[0] == 2.0
+    cp1, ri1, v1 = oracle.gen_lp_basis(600, 6, 6, 0.5, 1, 0.3)
+    cp2, ri2, v2 = oracle.gen_lp_basis(600, 6, 6, 0.5, 2, 0.3)
+    g = blu.BLU(600, max(len(ri1), len(ri2)))
+    for cp, ri, v in ((cp1, ri1, v1), (cp2, ri2, v2), (cp1, ri1, v1)):
+        o = oracle.OracleBLU(600, 32 * len(ri))
+        assert g.factorize(cp[:-1], cp[1:], ri, v) == o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+        util.assert_same_factors(g.get_factors(), o.get_factors())
+
+
+def test_small_initial_capacity_forces_device_side_growth(blu, oracle):
+    """BLU::new(m, tiny): L/U/arenas start small; the pivot kernel exits with NEED_*, the host grows /
+    compacts and relaunches (the device counterpart of blu.rs:105-115).  Results must not change."""
+    cp, ri, v = oracle.gen_lp_basis(1500, 8, 16, 0.2, 3, 1.0)
+    m = 1500
+    g = blu.BLU(m, 16)  # b_nz hint far too small
+    o = oracle.OracleBLU(m, 64 * len(ri))
+    o.set_fix_d3(True)
+    sg, so = g.factorize(cp[:-1], cp[1:], ri, v), o.factorize(cp[:-1], cp[1:], ri, v)
+    assert sg == so == K.OK
+    util.assert_same_factors(g.get_factors(), o.get_factors())
+    assert g.stat(K.STAT_DEV_RELAUNCHES) > 1
+
+
+def test_config_c2_full_parity(blu, oracle):
+    c = CONFIGS["C2"]
+    cp, ri, v = oracle.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
+    assert sg == K.OK and o.d3_hits() == 0
+    f = _assert_parity(g, o, sg, so, cp, ri, v)
+    util.check_factors(cp, ri, v, f)
+
+
+def test_config_c3_full_size(blu, oracle):
+    """BASELINE.json configs[2] at full size: parity against the oracle (it finishes in ~1 s) and the
+    size-independent properties: permutations, triangular structure, L*U == B[p,q], solve round trip."""
+    c = CONFIGS["C3"]
+    cp, ri, v = oracle.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, cap=16 * len(ri))
+    assert sg == K.OK and o.d3_hits() == 0 and g.stat(50) == 0
+    f = _assert_parity(g, o, sg, so, cp, ri, v)
+    util.check_factors(cp, ri, v, f)
+    m = c["m"]
+    rng = np.random.default_rng(1)
+    xs = rng.standard_normal(m)
+    B = util.csc(cp, ri, v, m)
+    x = g.solve_dense(B @ xs, "N")
+    assert np.abs(B @ x - B @ xs).max() <= 1e-9 * np.abs(B @ xs).max()
+    x = g.solve_dense(B.T @ xs, "T")
+    assert np.abs(B.T @ x - B.T @ xs).max() <= 1e-9 * np.abs(B.T @ xs).max()
+
+
+def test_generators_agree(blu, oracle):
+    """The library's generator (bench input) and the oracle's are the same function."""
+    for args in ((50, 4, 3, 0.5, 1, 0.3), (3000, 10, 9, 0.5, 7, 0.3)):
+        a = blu.gen_lp_basis(*args)
+        b = oracle.gen_lp_basis(*args)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
