@@ -35,6 +35,28 @@ __device__ __forceinline__ void insertion_sort_pairs(long long *key, double *val
     }
 }
 
+
+// Rank sort of one segment [b,e) of at most WSORT_MAX pairs by ONE wave, staged through this wave's
+// LDS slice (keys distinct).  Each lane ranks its elements against the whole segment.
+#define WSORT_MAX 256
+__device__ void wave_sort_segment(long long *key, double *val, int b, int e, int *lk, double *lv)
+{
+    const int lane = lane_id();
+    const int n = e - b;
+    for (int t = lane; t < n; t += 64) {
+        lk[t] = (int)key[b + t];
+        lv[t] = val[b + t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // LDS stores above before the LDS reads below (same wave)
+    for (int t = lane; t < n; t += 64) {
+        const int k = lk[t];
+        int r = 0;
+        for (int u = 0; u < n; u++) r += (lk[u] < k);
+        key[b + r] = k;
+        val[b + r] = lv[t];
+    }
+}
+
 // Workgroup-wide sort of one long segment [b,e) with distinct keys in [0,m): presence bitmap -> rank.
 // flag/rnk: int[m] scratch, stage_k/stage_v: scratch of >= e-b entries.
 __device__ void block_sort_segment(long long *key, double *val, int b, int e, int m, int *flag, int *rnk,
@@ -74,6 +96,8 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
     Scalars *S = D.s;
     __shared__ int sh[40];
     __shared__ double shd[40];
+    __shared__ int lds_k[16 * WSORT_MAX];
+    __shared__ double lds_v[16 * WSORT_MAX];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int m = D.m;
     if (S->status != ST_DONE) return;
@@ -113,7 +137,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
     // ---- L: column k = unit diagonal, then the stage-k column with rows renumbered by pinv and sorted
     // (get_factors.rs:86-113 scatters the row-wise copy in row order, which sorts each column)
     const int l_nz = D.lbeg[rank];
-    if (tid == 0) sh[34] = 0;
+    if (tid == 0) sh[34] = sh[35] = 0;
     __syncthreads();
     for (int k = tid; k <= m; k += nt) O.l_colptr[k] = (long long)D.lbeg[k] + k;
     for (int k = tid; k < m; k += nt) {
@@ -125,15 +149,21 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
             O.l_rowidx[ob + 1 + (p - b)] = D.pinv[D.lidx[p]];
             O.l_value[ob + 1 + (p - b)] = D.lval[p];
         }
-        if (e - b > 48) D.iw2[atomicAdd(&sh[34], 1)] = k;
+        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(&sh[35], 1)] = k; // long: from the top of iw2
+        else if (e - b > 24) D.iw2[atomicAdd(&sh[34], 1)] = k;            // medium: from the bottom
         else insertion_sort_pairs(O.l_rowidx, O.l_value, ob + 1, ob + 1 + (e - b));
     }
     __syncthreads();
     {
-        const int nlong = sh[34];
+        const int nmed = sh[34], nlong = sh[35];
         __syncthreads();
-        for (int r = 0; r < nlong; r++) {
+        for (int r = wave_id(); r < nmed; r += num_waves()) {
             const int k = D.iw2[r];
+            wave_sort_segment(O.l_rowidx, O.l_value, D.lbeg[k] + k + 1, D.lbeg[k + 1] + k + 1, &lds_k[wave_id() * WSORT_MAX],
+                              &lds_v[wave_id() * WSORT_MAX]);
+        }
+        for (int r = 0; r < nlong; r++) {
+            const int k = D.iw2[m - 1 - r];
             const int b = D.lbeg[k] + k + 1, e = D.lbeg[k + 1] + k + 1;
             block_sort_segment(O.l_rowidx, O.l_value, b, e, m, D.iw0, D.iw1, D.tnew, D.txrj, sh);
         }
@@ -165,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
     const int u_tot = base; // u_nz + m
     if (tid == 0) {
         O.u_colptr[m] = u_tot;
-        sh[34] = 0;
+        sh[34] = sh[35] = 0;
     }
     __syncthreads();
     for (int k = tid; k < rank; k += nt)
@@ -186,15 +216,21 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         O.u_value[e] = piv;
         pmin = fmin(pmin, fabs(piv));
         pmax = fmax(pmax, fabs(piv));
-        if (e - b > 48) D.iw2[atomicAdd(&sh[34], 1)] = k;
+        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(&sh[35], 1)] = k;
+        else if (e - b > 24) D.iw2[atomicAdd(&sh[34], 1)] = k;
         else insertion_sort_pairs(O.u_rowidx, O.u_value, b, e);
     }
     __syncthreads();
     {
-        const int nlong = sh[34];
+        const int nmed = sh[34], nlong = sh[35];
         __syncthreads();
-        for (int r = 0; r < nlong; r++) {
+        for (int r = wave_id(); r < nmed; r += num_waves()) {
             const int k = D.iw2[r];
+            const int b = (int)O.u_colptr[k];
+            wave_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], &lds_k[wave_id() * WSORT_MAX], &lds_v[wave_id() * WSORT_MAX]);
+        }
+        for (int r = 0; r < nlong; r++) {
+            const int k = D.iw2[m - 1 - r];
             const int b = (int)O.u_colptr[k];
             block_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], m, D.iw1, D.tnewr, D.tnew, D.txrj, sh);
         }

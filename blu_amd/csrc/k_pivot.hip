@@ -18,6 +18,18 @@
 //   * arithmetic: a = xrj / pivot; w -= a * c with separate roundings (no FMA)
 #include "blu_dev.h"
 
+// A failed check also raises this LDS flag, so the pivot loop can stop at the next pivot boundary
+// without polling the status word in HBM every iteration.
+__shared__ int g_pivot_err;
+#undef DEV_CHECK
+#define DEV_CHECK(S, cond)                               \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            set_error((S), ST_ERROR, __LINE__);          \
+            g_pivot_err = 1;                             \
+        }                                                \
+    } while (0)
+
 struct Sm {
     int pr, pc;
     int rank, rankdef, min_colnz, min_rownz;
@@ -1136,12 +1148,13 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
+    if (tid == 0) g_pivot_err = 0;
     __syncthreads();
 
     for (;;) {
         // ---- loop head: done / stop / error?
         if (tid == 0) {
-            if (S->status != ST_RUNNING) sm->exit_code = S->status;
+            if (g_pivot_err) sm->exit_code = ST_ERROR;
             else if (sm->rank + sm->rankdef >= m) sm->exit_code = ST_DONE;
             else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) sm->exit_code = ST_STOPPED;
             sm->need_search = sm->pc < 0;
