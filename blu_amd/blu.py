@@ -193,6 +193,11 @@ class BLU:
         if st != K.OK:
             raise BluError(st)
 
+    def dbg_set_no_fast(self, on=True):
+        """Run the general pivot paths only (k_pivot_fast.hip off): A/B of the two implementations."""
+        lib().blu_hip_dbg_set_no_fast.argtypes = [C.c_void_p, C.c_int]
+        lib().blu_hip_dbg_set_no_fast(self._h, int(bool(on)))
+
     def dbg_continue(self, stop_at):
         st = lib().blu_hip_dbg_continue(self._h, int(stop_at))
         if st in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):

@@ -67,7 +67,7 @@ struct DevLU {
     int maxsearch;
     int pad;
     int search_rows;
-    int pad1;
+    int no_fast;          // debug: 1 = general pivot paths only (k_pivot_fast.hip off)
     double droptol, abstol, reltol, stretch;
 
     // input matrix as handed over by the caller (device copies of the uint64 arrays)

@@ -51,6 +51,7 @@ struct blu_hip {
     double t_total, t_pivot;
     int relaunches;
     int block_threads; // workgroup size of the pivot kernel
+    int no_fast;       // debug: disable the LDS fast paths
     std::string err;
     int64_t stop_at;   // debug: -1 off
 };
@@ -119,6 +120,7 @@ static bool upload_desc(blu_hip *h)
     D.maxsearch = (int)std::min<int64_t>(h->maxsearch, kIntMax);
     D.pad = (int)h->pad;
     D.search_rows = (int)h->search_rows;
+    D.no_fast = h->no_fast;
     D.droptol = h->droptol;
     D.abstol = h->abstol;
     D.reltol = h->reltol;
@@ -170,6 +172,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->nfactorize = 0;
     h->stop_at = -1;
     h->block_threads = 1024;
+    h->no_fast = 0;
     memset(&h->D, 0, sizeof(DevLU));
     memset(&h->hs, 0, sizeof(Scalars));
     memset(&h->O, 0, sizeof(FinishOut));
@@ -666,6 +669,12 @@ extern "C" int blu_hip_dbg_set_stop(blu_hip *h, int64_t stop_at)
 {
     if (!h) return BLU_ERROR_ARGUMENT_MISSING;
     h->stop_at = stop_at;
+    return BLU_OK;
+}
+extern "C" int blu_hip_dbg_set_no_fast(blu_hip *h, int on)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    h->no_fast = on ? 1 : 0;
     return BLU_OK;
 }
 extern "C" int blu_hip_dbg_set_block(blu_hip *h, int threads)

@@ -30,7 +30,10 @@ __shared__ int g_pivot_err;
         }                                                \
     } while (0)
 
+#include "k_pivot_fast_types.h"
+
 struct Sm {
+    Fast fa;
     int pr, pc;
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
@@ -1117,6 +1120,33 @@ __device__ bool pivot_doubleton_col(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // the persistent pivot loop: factorize_bump (factorize_bump.rs:12-49) + pivot() (pivot.rs:48-112)
 // ------------------------------------------------------------------------------------------------
+#include "k_pivot_fast.hip"
+
+// set-up of a pivot for the general paths (after the general searches, or for a pivot that was
+// pending when the kernel left with NEED_*): line positions and the L/U room check of pivot.rs:70-81
+__device__ void setup_pivot_general(const DevLU &D, Sm *sm)
+{
+    Scalars *S = D.s;
+    const int pr = sm->pr, pc = sm->pc;
+    sm->fa.kind = 0;
+    if (pc < 0 || pr < 0) return;
+    sm->pcb = D.cbeg[pc];
+    sm->prb = D.rbeg[pr];
+    sm->nzc = D.clen[pc];
+    sm->nzr = D.rlen[pr];
+    sm->flag_small = 0;
+    sm->ncancel = 0;
+    DEV_CHECK(S, D.pinv[pr] == -1 && D.qinv[pc] == -1);
+    DEV_CHECK(S, sm->nzc >= 1 && sm->nzr >= 1);
+    if (sm->lused + (sm->nzc - 1) > D.lcap) {
+        sm->exit_code = ST_NEED_L;
+        sm->need = sm->nzc - 1;
+    } else if (sm->uused + (sm->nzr - 1) > D.ucap) {
+        sm->exit_code = ST_NEED_U;
+        sm->need = sm->nzr - 1;
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
     const DevLU &D = Ds[blockIdx.x];
@@ -1165,13 +1195,21 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
         // `need_search` is decided by thread 0 before the barrier above: sm->pc itself is rewritten by
         // the searching wave, so testing it here would race with slower waves.
-        if (sm->need_search) {
-            if (w == 0) {
-                if (D.search_rows == 0) markowitz_wave(D, sm);
-                else if (lane == 0) markowitz_serial(D, sm);
+        // The searching wave also lays out the pivot (positions, L/U room check, and for the two
+        // common pivot kinds the LDS working set of k_pivot_fast.hip) before the barrier.
+        if (w == 0) {
+            bool handled = false;
+            if (sm->need_search) {
+                if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast(D, sm);
+                if (!handled) {
+                    if (D.search_rows == 0) markowitz_wave(D, sm);
+                    else if (lane == 0) markowitz_serial(D, sm);
+                    wave_mem_sync();
+                }
             }
-            __syncthreads();
+            if (!handled && lane == 0) setup_pivot_general(D, sm);
         }
+        __syncthreads();
         const int pr = sm->pr, pc = sm->pc;
         if (pc < 0) { // no pivot found: the reference asserts (factorize_bump.rs:22)
             if (tid == 0) {
@@ -1193,29 +1231,13 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             continue;
         }
 
-        // ---- pivot(): room in L and U (pivot.rs:70-81), dispatch (:84-94)
-        if (tid == 0) {
-            sm->pcb = D.cbeg[pc];
-            sm->prb = D.rbeg[pr];
-            sm->nzc = D.clen[pc];
-            sm->nzr = D.rlen[pr];
-            sm->flag_small = 0;
-            sm->ncancel = 0;
-            DEV_CHECK(S, D.pinv[pr] == -1 && D.qinv[pc] == -1);
-            DEV_CHECK(S, sm->nzc >= 1 && sm->nzr >= 1);
-            if (sm->lused + (sm->nzc - 1) > D.lcap) {
-                sm->exit_code = ST_NEED_L;
-                sm->need = sm->nzc - 1;
-            } else if (sm->uused + (sm->nzr - 1) > D.ucap) {
-                sm->exit_code = ST_NEED_U;
-                sm->need = sm->nzr - 1;
-            }
-        }
-        __syncthreads();
+        // ---- pivot(): the room check of pivot.rs:70-81 was made by the searching wave; dispatch (:84-94)
         if (sm->exit_code) break;
         const int nz_col = sm->nzc, nz_row = sm->nzr;
-        bool ok;
-        if (nz_row == 1) ok = pivot_singleton_row(D, sm);
+        bool ok = true;
+        if (sm->fa.kind == 1) fast_small(D, sm);
+        else if (sm->fa.kind == 2) fast_scol(D, sm);
+        else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
         else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
         else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
         else ok = pivot_general(D, sm, nz_col - 1 <= 64);

@@ -1,0 +1,722 @@
+// k_pivot_fast.hip -- low-latency paths of the pivot loop (included by k_pivot.hip).
+//
+// The general paths in k_pivot.hip walk every line through HBM-resident metadata and mark arrays:
+// ~40 dependent memory round trips and 12 barriers per pivot.  For the two pivot kinds that make up
+// practically all pivots of LP-like bases -- pivot_small with a short pivot row, and
+// pivot_singleton_col -- this file keeps the per-pivot working set in LDS instead:
+//
+//   * Markowitz: the (<= 4) candidate columns are found by walking the count list first, then ALL
+//     their entries are evaluated in one flattened pass (lexicographic wave min over (cost, flat
+//     position) == the reference's sequential strict-< scan, markowitz.rs:80-122); the candidates'
+//     entries and the (begin,len,cap) of their rows are staged in LDS on the way.
+//   * The chosen pivot column, the pivot row and the (begin,len,cap) of every line they touch are
+//     laid out in LDS by the searching wave; membership tests "row in pivot column" / "column in
+//     pivot row" (the reference's `marked` array, pivot.rs:219-224, 337-339) are LDS hash sets.
+//   * Column and row updates of one pivot run concurrently (one line per wave); the rare numerical
+//     cancellation (pivot.rs:656-660) is repaired afterwards.
+//   * 4 barriers per pivot.
+//
+// Everything result-affecting (entry order inside lines, list order, arithmetic) is identical to
+// the general paths, which remain the fallback for all other shapes.
+
+__device__ __forceinline__ unsigned hslot(int k, int bits) { return ((unsigned)k * 2654435761u) >> (32 - bits); }
+__device__ __forceinline__ void hrow_insert(Fast *f, int k, int v)
+{
+    unsigned s = hslot(k, 8);
+    for (;;) {
+        const int old = atomicCAS(&f->hRowK[s], -1, k);
+        if (old == -1 || old == k) {
+            f->hRowV[s] = v;
+            return;
+        }
+        s = (s + 1) & (HROW - 1);
+    }
+}
+__device__ __forceinline__ int hrow_lookup(const Fast *f, int k)
+{
+    unsigned s = hslot(k, 8);
+    for (;;) {
+        const int kk = f->hRowK[s];
+        if (kk == k) return f->hRowV[s];
+        if (kk == -1) return 0;
+        s = (s + 1) & (HROW - 1);
+    }
+}
+__device__ __forceinline__ void hcol_insert(Fast *f, int k)
+{
+    unsigned s = hslot(k, 10);
+    for (;;) {
+        const int old = atomicCAS(&f->hColK[s], -1, k);
+        if (old == -1 || old == k) return;
+        s = (s + 1) & (HCOL - 1);
+    }
+}
+__device__ __forceinline__ bool hcol_has(const Fast *f, int k)
+{
+    unsigned s = hslot(k, 10);
+    for (;;) {
+        const int kk = f->hColK[s];
+        if (kk == k) return true;
+        if (kk == -1) return false;
+        s = (s + 1) & (HCOL - 1);
+    }
+}
+struct InHCol {
+    const Fast *f;
+    __device__ __forceinline__ bool operator()(int e) const { return hcol_has(f, e); }
+};
+struct InHRow {
+    const Fast *f;
+    __device__ __forceinline__ bool operator()(int e) const { return hrow_lookup(f, e) > 0; }
+};
+
+// Batched list_move (see wave_list_move_batch in k_pivot.hip) with the set of moved elements given
+// as a membership predicate instead of a mark array.  elems/keys may live in LDS.
+template <class InSet>
+__device__ int wave_list_move_batch_set(int *flink, int *blink, int nelem, const int *elems, const int *keys, int n,
+                                        InSet inS, int big)
+{
+    const int lane = lane_id();
+    int minkey = big;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int q = c0 + lane;
+        if (q < n && keys[q] >= 0) {
+            const int e = elems[q];
+            const int p = blink[e];
+            int nx = flink[e];
+            const bool prev_marked = p < nelem && inS(p);
+            if (!prev_marked) {
+                for (int guard = 0; nx < nelem && inS(nx) && guard <= n; guard++) nx = flink[nx];
+                flink[p] = nx;
+                blink[nx] = p;
+            }
+        }
+    }
+    wave_mem_sync();
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int q = c0 + lane;
+        int key = q < n ? keys[q] : -1;
+        const int e = key >= 0 ? elems[q] : 0;
+        bool act = key >= 0;
+        if (act && key > 0) minkey = min(minkey, key);
+        unsigned long long active = __ballot(act);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int k = __shfl(key, leader);
+            const unsigned long long grp = __ballot(act && key == k);
+            const int tail = blink[nelem + k];
+            const unsigned long long below = grp & lanes_below(lane);
+            const unsigned long long above = grp & ~((2ull << lane) - 1ull);
+            const int prevl = below ? 63 - __clzll((long long)below) : 0;
+            const int nextl = above ? __ffsll((long long)above) - 1 : 0;
+            const int pe = __shfl(e, prevl), ne = __shfl(e, nextl);
+            if (act && key == k) {
+                blink[e] = below ? pe : tail;
+                flink[e] = above ? ne : nelem + k;
+                if (!below) flink[tail] = e;
+                if (!above) blink[nelem + k] = e;
+                act = false;
+            }
+            active &= ~grp;
+        }
+        wave_mem_sync();
+    }
+    return wave_min_i(minkey);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flattened Markowitz search + pivot set-up, ONE wave.  Returns false if the shape is outside what
+// this path handles (nothing has been modified then; the caller runs the general search).
+// On return true: sm->pr/pc set (pr = -1: empty column; pc = -1: error), and for a real pivot
+// sm->pcb/prb/nzc/nzr, the L/U room check (sm->exit_code) and fa->kind.
+// ------------------------------------------------------------------------------------------------
+__device__ bool markowitz_fast(const DevLU &D, Sm *sm)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (K < 1 || K > KCMAX) return false;
+    if (lane == 0) fa->kind = 0;
+
+    const int h0 = D.cflink[m];
+    if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
+        if (lane == 0) {
+            sm->pc = h0;
+            sm->pr = -1;
+        }
+        return true;
+    }
+    // ---- first K columns in list order, starting at the first non-empty count list >= min_colnz
+    int ncand = 0, total = 0;
+    int nz = sm->min_colnz;
+    bool bad = false;
+    while (ncand < K && nz <= m && !bad) {
+        const int k = nz + lane;
+        const int h = k <= m ? D.cflink[m + k] : m + k;
+        unsigned long long ne = __ballot(k <= m && h != m + k);
+        while (ne && ncand < K && !bad) {
+            const int b = __ffsll((long long)ne) - 1;
+            ne &= ne - 1;
+            int j = __shfl(h, b);
+            const int znz = nz + b;
+            int guard = 0;
+            while (j < m && ncand < K) {
+                const int fl = D.cflink[j];
+                const int cb = D.cbeg[j], cl = D.clen[j];
+                const double cmx = D.colmax[j];
+                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = znz;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = cl;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                total += cl;
+                ncand++;
+                j = fl;
+            }
+        }
+        nz += 64;
+    }
+    if (bad || ncand == 0) { // reference: assert / D2 / "no pivot found" assert
+        DEV_CHECK(S, false);
+        if (lane == 0) {
+            sm->pc = -1;
+            sm->pr = -1;
+        }
+        return true;
+    }
+    if (total > STGMAX) return false;
+    if (lane == 0) fa->cOff[ncand] = total;
+    wave_mem_sync();
+    const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
+              off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
+
+    // ---- all candidate entries at once: cost (nz-1)(rownz-1) of every eligible entry
+    const long long BIG = 0x7fffffffffffffffLL;
+    long long mcb = BIG;
+    int fb = 0x7fffffff;
+    for (int base = 0; base < total; base += 64) {
+        const int f = base + lane;
+        if (f < total) {
+            const int c = (f >= off1) + (f >= off2) + (f >= off3);
+            const int e = f - fa->cOff[c];
+            const int pos = fa->cB[c] + e;
+            const int idx = D.cidx[pos];
+            const double val = D.cval[pos];
+            const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+            fa->sI[f] = idx;
+            fa->sV[f] = val;
+            fa->sB[f] = rb;
+            fa->sL[f] = rl;
+            fa->sC[f] = rc;
+            const double cmx = fa->cMx[c];
+            const double tol = fmax(D.abstol, D.reltol * cmx);
+            const double x = fabs(val);
+            if (!(x == 0.0 || x < tol)) {
+                const long long mc = (long long)(fa->cNz[c] - 1) * (long long)(rl - 1);
+                if (mc < mcb) { // f grows with base: strict < keeps the earliest position per lane
+                    mcb = mc;
+                    fb = f;
+                }
+            }
+        }
+    }
+    const long long mn = wave_min_ll(mcb);
+    if (mn == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
+        DEV_CHECK(S, false);
+        if (lane == 0) {
+            sm->pc = -1;
+            sm->pr = -1;
+        }
+        return true;
+    }
+    const int fsel = wave_min_i(mcb == mn ? fb : 0x7fffffff); // first-seen entry wins ties
+    wave_mem_sync();
+    const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
+    const int pc = fa->cJ[csel], pr = fa->sI[fsel];
+    const int nzc = fa->cL[csel], pcb = fa->cB[csel], where = fsel - fa->cOff[csel];
+    const int nzr = fa->sL[fsel], prb = fa->sB[fsel];
+    if (lane == 0) {
+        sm->pr = pr;
+        sm->pc = pc;
+        sm->pcb = pcb;
+        sm->prb = prb;
+        sm->nzc = nzc;
+        sm->nzr = nzr;
+        sm->nsearch += ncand;
+        sm->min_colnz = fa->cNz[0];
+        sm->flag_small = 0;
+        sm->ncancel = 0;
+        fa->anycancel = 0;
+        // room in L and U (pivot.rs:70-81)
+        if (sm->lused + (nzc - 1) > D.lcap) {
+            sm->exit_code = ST_NEED_L;
+            sm->need = nzc - 1;
+        } else if (sm->uused + (nzr - 1) > D.ucap) {
+            sm->exit_code = ST_NEED_U;
+            sm->need = nzr - 1;
+        }
+    }
+    DEV_CHECK(S, nzr >= 1 && nzc >= 1);
+    int kind = 0;
+    if (nzr >= 2 && nzr <= PRMAX) {
+        if (nzc == 1) kind = 2;
+        else if (nzc >= 3 && nzc <= PCMAX) kind = 1;
+    }
+    if (kind == 0) return true;
+
+    // ---- pivot column into LDS; kind 1: pivot swapped to the front (pivot.rs:169-170)
+    const int coff = fa->cOff[csel];
+    for (int e = lane; e < nzc; e += 64) {
+        const int slot = (e == where) ? 0 : (e == 0 ? where : e);
+        fa->pcI[slot] = fa->sI[coff + e];
+        fa->pcV[slot] = fa->sV[coff + e];
+        fa->prB[slot] = fa->sB[coff + e];
+        fa->prL[slot] = fa->sL[coff + e];
+        fa->prC[slot] = fa->sC[coff + e];
+    }
+    // ---- pivot row into LDS; kind 1: pivot column swapped to the front (pivot.rs:185)
+    int jq[PRMAX / 64];
+    int wpos = -1;
+#pragma unroll
+    for (int c = 0; c < PRMAX / 64; c++) {
+        const int q = c * 64 + lane;
+        jq[c] = q < nzr ? D.ridx[prb + q] : -1;
+        const unsigned long long hb = __ballot(jq[c] == pc);
+        if (hb) wpos = c * 64 + __ffsll((long long)hb) - 1;
+    }
+    if (wpos < 0) {
+        DEV_CHECK(S, false);
+        if (lane == 0) sm->pc = -1;
+        return true;
+    }
+    for (int s = lane; s < HROW; s += 64) fa->hRowK[s] = -1;
+    for (int s = lane; s < HCOL; s += 64) fa->hColK[s] = -1;
+    long long gc = 0, gr = 0;
+#pragma unroll
+    for (int c = 0; c < PRMAX / 64; c++) {
+        const int q = c * 64 + lane;
+        if (q < nzr) {
+            const int j = jq[c];
+            const int slot = kind == 1 ? ((q == wpos) ? 0 : (q == 0 ? wpos : q)) : q;
+            const int tb = D.cbeg[j], tl = D.clen[j], tc = D.ccap[j];
+            fa->tJ[slot] = j;
+            fa->tB[slot] = tb;
+            fa->tL[slot] = tl;
+            fa->tC[slot] = tc;
+            hcol_insert(fa, j);
+            if (kind == 1 && q != wpos) {
+                const int n = tl + nzc - 1;
+                gc += n + stretch_of(D.stretch, n) + D.pad;
+            }
+        }
+    }
+    if (kind == 1) {
+        for (int p = 1 + lane; p < nzc; p += 64) {
+            hrow_insert(fa, fa->pcI[p], p);
+            const int n = fa->prL[p] + nzr - 1;
+            gr += n + stretch_of(D.stretch, n) + D.pad;
+        }
+        gc = wave_sum_ll(gc);
+        gr = wave_sum_ll(gr);
+        if ((long long)sm->cused + gc > (long long)D.carena_cap || (long long)sm->rused + gr > (long long)D.rarena_cap)
+            kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
+    }
+    if (lane == 0) {
+        fa->kind = kind;
+        fa->where = wpos;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kind 1: pivot_small (pivot.rs:460-833), column q of the pivot row, ONE wave
+// ------------------------------------------------------------------------------------------------
+__device__ void fast_col(const DevLU &D, Sm *sm, int q, double *work)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int pr = sm->pr, cnz1 = sm->nzc - 1;
+    const double pivot = fa->pcV[0];
+    const int j = fa->tJ[q], cb = fa->tB[q], cl = fa->tL[q], cap = fa->tC[q];
+
+    int nkept = 0, where = -1, first_idx = 0;
+    double xrj = 0.0, first_val = 0.0, cmxl = 0.0;
+    // registers of the first chunk are reused in pass 2 when the column fits one chunk
+    int idx0 = 0, t0r = 0;
+    double val0 = 0.0;
+    bool keep0 = false;
+    for (int c = 0; c < cl; c += 64) {
+        const int e = c + lane;
+        const bool v = e < cl;
+        const int idx = v ? D.cidx[cb + e] : 0;
+        const double val = v ? D.cval[cb + e] : 0.0;
+        const int mk = v ? hrow_lookup(fa, idx) : 0;
+        const bool keep = v && mk == 0;
+        if (v && mk > 0) work[mk - 1] = val;
+        const unsigned long long kb = __ballot(keep);
+        const int t = nkept + __popcll(kb & lanes_below(lane));
+        const bool ispr = keep && idx == pr;
+        const unsigned long long pb = __ballot(ispr);
+        if (pb) {
+            const int src = __ffsll((long long)pb) - 1;
+            where = __shfl(t, src);
+            xrj = __shfl(val, src);
+        }
+        const unsigned long long fb = __ballot(keep && t == 0);
+        if (fb) {
+            const int src = __ffsll((long long)fb) - 1;
+            first_idx = __shfl(idx, src);
+            first_val = __shfl(val, src);
+        }
+        if (keep && !ispr) {
+            const double x = fabs(val);
+            if (x > cmxl) cmxl = x;
+        }
+        if (c == 0) {
+            idx0 = idx;
+            val0 = val;
+            keep0 = keep;
+            t0r = t;
+        }
+        nkept += __popcll(kb);
+    }
+    DEV_CHECK(S, where >= 0);
+    const int nk1 = nkept - 1;
+    const int need_max = nk1 + cnz1;
+    const bool reloc = need_max > cap;
+    int dst = cb, newcap = cap;
+    if (reloc) {
+        newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(&sm->cused, newcap);
+        dst = __shfl(nb, 0);
+    }
+    if (cl <= 64) {
+        if (keep0 && t0r != where && t0r > 0) {
+            D.cidx[dst + t0r - 1] = idx0;
+            D.cval[dst + t0r - 1] = val0;
+        }
+    } else {
+        int nk = 0;
+        for (int c = 0; c < cl; c += 64) {
+            const int e = c + lane;
+            const bool v = e < cl;
+            const int idx = v ? D.cidx[cb + e] : 0;
+            const double val = v ? D.cval[cb + e] : 0.0;
+            const bool keep = v && hrow_lookup(fa, idx) == 0;
+            const unsigned long long kb = __ballot(keep);
+            const int t = nk + __popcll(kb & lanes_below(lane));
+            if (keep && t != where && t > 0) {
+                D.cidx[dst + t - 1] = idx;
+                D.cval[dst + t - 1] = val;
+            }
+            nk += __popcll(kb);
+        }
+    }
+    if (where > 0 && lane == 0) {
+        D.cidx[dst + where - 1] = first_idx;
+        D.cval[dst + where - 1] = first_val;
+    }
+    const double a = xrj / pivot;
+    const int put = dst + nk1;
+    const bool p = lane < cnz1;
+    double x = 0.0;
+    int ri = 0;
+    if (p) {
+        x = mulsub(work[lane], a, fa->pcV[1 + lane]);
+        ri = fa->pcI[1 + lane];
+        work[lane] = 0.0;
+    }
+    const double ax = fabs(x);
+    const bool kx = p && ax > D.droptol;
+    const unsigned long long kb = __ballot(kx);
+    if (kx) {
+        const int d = __popcll(kb & lanes_below(lane));
+        D.cidx[put + d] = ri;
+        D.cval[put + d] = x;
+        if (ax > cmxl) cmxl = ax;
+    }
+    const unsigned long long mask = __ballot(p && !kx);
+    const int nadd = __popcll(kb);
+    const double cmx = wave_max_d(cmxl);
+    if (lane == 0) {
+        const int newlen = nk1 + nadd;
+        D.cbeg[j] = dst;
+        D.clen[j] = newlen;
+        D.ccap[j] = newcap;
+        D.colmax[j] = cmx;
+        fa->tNew[q] = newlen;
+        fa->tX[q] = xrj;
+        fa->tM[q] = mask;
+        if (mask) fa->anycancel = 1;
+        if (reloc) atomicAdd((unsigned long long *)&sm->nexpand, 1ull);
+        if (mask >> 31) atomicAdd((unsigned long long *)&sm->d3, (unsigned long long)__popcll(mask >> 31));
+        if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
+    }
+}
+
+// kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
+// cancelled by fast_col are removed afterwards by fast_fixrow.
+__device__ void fast_row(const DevLU &D, Sm *sm, int p)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int pc = sm->pc, rnz1 = sm->nzr - 1;
+    const int i = fa->pcI[p], rb = fa->prB[p], rl = fa->prL[p], cap = fa->prC[p];
+
+    int nk = 0;
+    bool found = false;
+    int j0 = -1, t0r = 0;
+    bool keep0 = false;
+    for (int c = 0; c < rl; c += 64) {
+        const int e = c + lane;
+        const bool v = e < rl;
+        const int j = v ? D.ridx[rb + e] : -1;
+        const bool keep = v && !hcol_has(fa, j);
+        if (__ballot(v && j == pc)) found = true;
+        const unsigned long long kb = __ballot(keep);
+        if (c == 0) {
+            j0 = j;
+            keep0 = keep;
+            t0r = __popcll(kb & lanes_below(lane));
+        }
+        nk += __popcll(kb);
+    }
+    DEV_CHECK(S, found);
+    const int need_max = nk + rnz1;
+    const bool reloc = need_max > cap;
+    int dst = rb, newcap = cap;
+    if (reloc) {
+        newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(&sm->rused, newcap);
+        dst = __shfl(nb, 0);
+    }
+    if (rl <= 64) {
+        if (keep0) D.ridx[dst + t0r] = j0;
+    } else {
+        int t0 = 0;
+        for (int c = 0; c < rl; c += 64) {
+            const int e = c + lane;
+            const bool v = e < rl;
+            const int j = v ? D.ridx[rb + e] : -1;
+            const bool keep = v && !hcol_has(fa, j);
+            const unsigned long long kb = __ballot(keep);
+            if (keep) D.ridx[dst + t0 + __popcll(kb & lanes_below(lane))] = j;
+            t0 += __popcll(kb);
+        }
+    }
+    for (int q = 1 + lane; q <= rnz1; q += 64) D.ridx[dst + nk + q - 1] = fa->tJ[q];
+    if (lane == 0) {
+        D.rbeg[i] = dst;
+        D.rlen[i] = nk + rnz1;
+        D.rcap[i] = newcap;
+        fa->rNew[p] = nk + rnz1;
+        fa->rKept[p] = nk;
+        fa->rDst[p] = dst;
+        if (reloc) atomicAdd((unsigned long long *)&sm->nexpand, 1ull);
+    }
+}
+
+// rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
+__device__ void fast_fixrow(const DevLU &D, Sm *sm, int p)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    const int rnz1 = sm->nzr - 1;
+    const int dst = fa->rDst[p], nk = fa->rKept[p];
+    int na = 0;
+    for (int c = 0; c < rnz1; c += 64) {
+        const int q = 1 + c + lane;
+        const bool ok = q <= rnz1 && ((fa->tM[q] >> (p - 1)) & 1ull) == 0;
+        const unsigned long long kb = __ballot(ok);
+        if (ok) D.ridx[dst + nk + na + __popcll(kb & lanes_below(lane))] = fa->tJ[q];
+        na += __popcll(kb);
+    }
+    if (lane == 0) {
+        D.rlen[fa->pcI[p]] = nk + na;
+        fa->rNew[p] = nk + na;
+    }
+}
+
+// U row from the LDS copies (pivot.rs:306-312): slots q0..q1 of the pivot row except skipq
+__device__ void fast_write_u(const DevLU &D, Sm *sm, int q0, int q1, int skipq)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    int put = sm->uused;
+    for (int c = q0; c <= q1; c += 64) {
+        const int q = c + lane;
+        const bool v = q <= q1 && q != skipq;
+        const double x = v ? fa->tX[q] : 0.0;
+        const bool k = v && fabs(x) > D.droptol;
+        const unsigned long long kb = __ballot(k);
+        if (k) {
+            const int d = put + __popcll(kb & lanes_below(lane));
+            D.uidx[d] = fa->tJ[q];
+            D.uval[d] = x;
+        }
+        put += __popcll(kb);
+    }
+    if (lane == 0) {
+        D.ubeg[sm->rank + 1] = put;
+        sm->uused = put;
+    }
+}
+
+// L column from the LDS copy (pivot.rs:404-416): slots 1..cnz1
+__device__ void fast_write_l(const DevLU &D, Sm *sm)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    const int cnz1 = sm->nzc - 1;
+    const double pivot = fa->pcV[0];
+    int put = sm->lused;
+    for (int c = 1; c <= cnz1; c += 64) {
+        const int p = c + lane;
+        const bool v = p <= cnz1;
+        const double x = v ? fa->pcV[p] / pivot : 0.0;
+        const bool k = v && fabs(x) > D.droptol;
+        const unsigned long long kb = __ballot(k);
+        if (k) {
+            const int d = put + __popcll(kb & lanes_below(lane));
+            D.lidx[d] = fa->pcI[p];
+            D.lval[d] = x;
+        }
+        put += __popcll(kb);
+    }
+    if (lane == 0) {
+        D.lbeg[sm->rank + 1] = put;
+        sm->lused = put;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kind 1, whole workgroup
+// ------------------------------------------------------------------------------------------------
+__device__ void fast_small(const DevLU &D, Sm *sm)
+{
+    const int w = wave_id(), nw = num_waves(), lane = lane_id();
+    const int m = D.m;
+    Fast *fa = &sm->fa;
+    const int pr = sm->pr, pc = sm->pc;
+    const int cnz1 = sm->nzc - 1, rnz1 = sm->nzr - 1;
+    DEV_CHECK(D.s, fa->pcV[0] != 0.0);
+
+    double *work = &sm->swork[w * 64];
+    const int ntask = rnz1 + cnz1;
+    for (int t = w; t < ntask; t += nw) {
+        if (t < rnz1) fast_col(D, sm, t + 1, work);
+        else fast_row(D, sm, t - rnz1 + 1);
+    }
+    __syncthreads();
+    if (fa->anycancel) {
+        for (int p = 1 + w; p <= cnz1; p += nw) fast_fixrow(D, sm, p);
+        __syncthreads();
+    }
+    if (w == 0) {
+        fast_write_u(D, sm, 1, rnz1, -1);
+        if (lane == 0) {
+            D.colmax[pc] = fa->pcV[0];
+            D.clen[pc] = 0;
+            D.rlen[pr] = 0;
+            sm->kinds[3]++;
+        }
+    }
+    if (w == 1 % nw) fast_write_l(D, sm);
+    if (w == 2 % nw) {
+        if (lane == 0) list_remove1(D.cflink, D.cblink, pc);
+        wave_mem_sync();
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa}, m + 2);
+        if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
+    }
+    if (D.search_rows && w == 3 % nw) {
+        if (lane == 0) list_remove1(D.rflink, D.rblink, pr);
+        wave_mem_sync();
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2);
+        if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
+// ------------------------------------------------------------------------------------------------
+__device__ void fast_scol(const DevLU &D, Sm *sm)
+{
+    const int w = wave_id(), nw = num_waves(), lane = lane_id();
+    const int m = D.m;
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int pr = sm->pr, pc = sm->pc, rl = sm->nzr, wq = fa->where;
+    DEV_CHECK(S, fa->pcV[0] != 0.0 && fa->pcI[0] == pr);
+
+    for (int q = w; q < rl; q += nw) {
+        if (q == wq) {
+            if (lane == 0) fa->tNew[q] = -1;
+            continue;
+        }
+        const int j = fa->tJ[q], cb = fa->tB[q], cl = fa->tL[q];
+        int where = -1;
+        double xrj = 0.0, cmxl = 0.0;
+        for (int c = 0; c < cl; c += 64) {
+            const int e = c + lane;
+            const bool v = e < cl;
+            const int idx = v ? D.cidx[cb + e] : -1;
+            const double val = v ? D.cval[cb + e] : 0.0;
+            const unsigned long long hb = __ballot(v && idx == pr);
+            if (hb) {
+                const int src = __ffsll((long long)hb) - 1;
+                where = c + src;
+                xrj = __shfl(val, src);
+            }
+            if (v && idx != pr) {
+                const double x = fabs(val);
+                if (x > cmxl) cmxl = x;
+            }
+        }
+        DEV_CHECK(S, where >= 0);
+        const double cmx = wave_max_d(cmxl);
+        if (lane == 0 && where >= 0) {
+            D.cidx[cb + where] = D.cidx[cb + cl - 1]; // last entry into the hole (pivot.rs:991-993)
+            D.cval[cb + where] = D.cval[cb + cl - 1];
+            D.clen[j] = cl - 1;
+            D.colmax[j] = cmx;
+            fa->tNew[q] = cl - 1;
+            fa->tX[q] = xrj;
+            if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        fast_write_u(D, sm, 0, rl - 1, wq);
+        if (lane == 0) {
+            D.lbeg[sm->rank + 1] = sm->lused; // empty column in L
+            D.colmax[pc] = fa->pcV[0];
+            D.clen[pc] = 0;
+            D.rlen[pr] = 0;
+            sm->kinds[1]++;
+        }
+    }
+    if (w == 1 % nw) {
+        if (lane == 0) {
+            list_remove1(D.cflink, D.cblink, pc);
+            if (D.search_rows) list_remove1(D.rflink, D.rblink, pr);
+        }
+        wave_mem_sync();
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa}, m + 2);
+        if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
+    }
+    __syncthreads();
+}
