@@ -5,4 +5,5 @@ the reference's `struct BLU`.  Nothing here imports the CPU oracle (oracle/): th
 infrastructure.
 """
 from . import keys  # noqa: F401
-from .blu import BLU, BluError, build_library, gen_lp_basis, lib  # noqa: F401
+from . import blu  # noqa: F401
+from .blu import BLU, BluError, build_library, factorize_batch, gen_lp_basis, lib  # noqa: F401

@@ -23,7 +23,7 @@ import numpy as np
 from . import keys as K
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libblu_hip.so")
+_LIB_PATH = os.environ.get("BLU_HIP_LIB") or os.path.join(_HERE, "libblu_hip.so")  # BLU_HIP_LIB: diagnostic builds
 _LIB = None
 
 _i64p = C.POINTER(C.c_int64)
@@ -102,6 +102,46 @@ def gen_lp_basis(m, k, bw, tri_frac, seed, offscale=1.0):
     nnz = lib().blu_hip_gen_lp_basis(m, k, bw, float(tri_frac), float(offscale), seed,
                                      _p(colptr, _u64p), _p(rowidx, _u64p), _p(value, _f64p))
     return colptr, rowidx[:nnz].copy(), value[:nnz].copy()
+
+
+def factorize_batch(handles, mats=None, device_ptrs=None, block=None):
+    """Factorize len(handles) independent bases concurrently on one GPU (one workgroup per basis).
+
+    mats: list of (colptr, rowidx, values) host CSC triples, or
+    device_ptrs: list of (p_begin, p_end, p_i, p_x, nnz_len) raw device pointers (inputs already in HBM).
+    Returns the list of per-handle statuses (reference Status numbering)."""
+    n = len(handles)
+    L = lib()
+    L.blu_hip_factorize_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p]
+    L.blu_hip_dbg_set_batch_block.argtypes = [C.c_void_p, C.c_int]
+    if block:
+        L.blu_hip_dbg_set_batch_block(handles[0]._h, int(block))
+    hs = (C.c_void_p * n)(*[h._h for h in handles])
+    pb, pe, pi, px = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    ln = (C.c_uint64 * n)()
+    keep = []
+    if device_ptrs is not None:
+        for k, (b, e, i, x, nn) in enumerate(device_ptrs):
+            pb[k], pe[k], pi[k], px[k], ln[k] = b, e, i, x, int(nn)
+        on_dev = 1
+    else:
+        for k, (cp, ri, v) in enumerate(mats):
+            cp = np.ascontiguousarray(cp, dtype=np.uint64)
+            ri = np.ascontiguousarray(ri, dtype=np.uint64)
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append((cp, ri, v))
+            pb[k], pe[k], pi[k], px[k], ln[k] = cp.ctypes.data, cp.ctypes.data + 8, ri.ctypes.data, v.ctypes.data, len(ri)
+        on_dev = 0
+    st = (C.c_int * n)()
+    rc = L.blu_hip_factorize_batch(hs, n, pb, pe, pi, px, ln, on_dev, st)
+    out = [int(s) for s in st]
+    if rc in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY) and all(s >= 0 for s in out):
+        raise BluError(rc, handles[0].last_error())
+    for h, s in zip(handles, out):
+        if s in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):
+            raise BluError(s, h.last_error())
+    return out
 
 
 class BLU:

@@ -58,6 +58,7 @@ struct Scalars {
     double min_pivot, max_pivot;
     double onenorm, infnorm;
     double norm_l, norm_u, normest_l_inv, normest_u_inv, condest_l, condest_u, residual_test;
+    long long prof[8];    // diagnostic build only (-DBLU_PROFILE): shader-clock ticks per phase of the pivot loop
 };
 
 struct DevLU {

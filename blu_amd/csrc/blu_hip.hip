@@ -33,10 +33,13 @@ struct blu_hip {
     int64_t nupdate;   // -1 = None
     int64_t nfactorize;
     DevLU D;           // host copy of the device descriptor (device pointers inside)
-    DevLU *dD;         // device copy
+    DevLU *dD;         // device copy (own slot)
+    DevLU *dslot;      // where the descriptor currently lives on the device: dD, or a slot of a batch array
     Scalars hs;        // last downloaded scalars
     FinishOut O;       // device output buffers of get_factors
     FinishOut *dO;
+    FinishOut *oslot;
+    int batch_block;   // workgroup size of the pivot kernel when this handle leads a batch
     int64_t out_lcap, out_ucap;
     // owned device copies of the caller's B (blu_hip_factorize with host arrays)
     unsigned long long *ob_begin, *ob_end, *ob_i;
@@ -125,7 +128,7 @@ static bool upload_desc(blu_hip *h)
     D.abstol = h->abstol;
     D.reltol = h->reltol;
     D.stretch = h->stretch;
-    HIP_TRY(h, hipMemcpy(h->dD, &D, sizeof(DevLU), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dslot, &D, sizeof(DevLU), hipMemcpyHostToDevice));
     return true;
 }
 static bool download_scalars(blu_hip *h)
@@ -206,6 +209,9 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     ok = ok && dalloc(h, &h->O.rowperm, M) && dalloc(h, &h->O.colperm, M) && dalloc(h, &h->O.l_colptr, M + 1) && dalloc(h, &h->O.u_colptr, M + 1);
     ok = ok && dalloc(h, &h->d_rhs, M) && dalloc(h, &h->d_lhs, M) && dalloc(h, &h->lvl_l, M + 2) && dalloc(h, &h->lvl_u, M + 2);
     if (ok) ok = hip_ok(h, hipMemset(D.gwork, 0, 16 * (M + 1) * sizeof(double)), "hipMemset");
+    h->dslot = h->dD;
+    h->oslot = h->dO;
+    h->batch_block = 256;
     if (ok) ok = hip_ok(h, hipStreamCreate(&h->stream), "hipStreamCreate");
     for (int k = 0; ok && k < 4; k++) ok = hip_ok(h, hipEventCreate(&h->ev[k]), "hipEventCreate");
     if (!ok) {
@@ -317,6 +323,8 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 56: return (double)s.npivot_kind[5];
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
+    case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67:
+        return (double)s.prof[key - 60]; // diagnostic build only
     default: return NAN;
     }
 }
@@ -376,7 +384,7 @@ static bool compact_file(blu_hip *h, int which, int need)
     HIP_TRY(h, hipMemcpy(d_pi, &nidx, sizeof(int *), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(d_pv, &nval, sizeof(double *), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(d_cap, &capi, sizeof(int), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->dD, which, d_pi, d_pv, d_cap);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->dslot, which, d_pi, d_pv, d_cap);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dfree(d_pi); dfree(d_pv); dfree(d_cap);
     if (which) {
@@ -405,192 +413,11 @@ static bool ensure_out(blu_hip *h, int64_t ln, int64_t un)
         if (!dalloc(h, &h->O.u_rowidx, (size_t)un) || !dalloc(h, &h->O.u_value, (size_t)un)) return false;
         h->out_ucap = un;
     }
-    HIP_TRY(h, hipMemcpy(h->dO, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->oslot, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------
-// the factorize driver: factorize() (src/factorize.rs:34-182) + BLU::factorize's realloc loop
-// ---------------------------------------------------------------------------------------------
-static int finish_stage(blu_hip *h);
-
-// pivot loop (continued until done / stopped), then build + read-out
-static int pivot_stage(blu_hip *h)
-{
-    DevLU &D = h->D;
-    for (int iter = 0; iter < 200; iter++) {
-        (void)hipEventRecord(h->ev[2], h->stream);
-        hipLaunchKernelGGL(k_pivot_loop, dim3(1), dim3(h->block_threads), 0, h->stream, h->dD, (int)h->stop_at);
-        (void)hipEventRecord(h->ev[3], h->stream);
-        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_pivot_loop")) return BLU_ERROR_DEVICE;
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, h->ev[2], h->ev[3]);
-        h->t_pivot += 1e-3 * ms;
-        h->relaunches++;
-        if (!download_scalars(h)) return BLU_ERROR_DEVICE;
-        const int st = h->hs.status;
-        if (st == ST_DONE) return finish_stage(h);
-        if (st == ST_STOPPED) return BLU_STOPPED_STATUS;
-        bool ok = true;
-        if (st == ST_NEED_L) ok = grow_l(h, h->hs.need) && upload_desc(h);
-        else if (st == ST_NEED_U) ok = grow_u(h, h->hs.need) && upload_desc(h);
-        else if (st == ST_NEED_CW) ok = compact_file(h, 0, h->hs.need);
-        else if (st == ST_NEED_RW) ok = compact_file(h, 1, h->hs.need);
-        else {
-            char buf[128];
-            snprintf(buf, sizeof buf, "pivot loop failed: device status %d at k_pivot.hip/blu_dev.h line %d", st, h->hs.err_line);
-            h->err = buf;
-            return BLU_ERROR_DEVICE;
-        }
-        if (!ok) return h->err.find("hipMalloc") != std::string::npos ? BLU_ERROR_OUT_OF_MEMORY : BLU_ERROR_DEVICE;
-        if (!set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
-    }
-    h->err = "pivot loop: too many relaunches";
-    return BLU_ERROR_DEVICE;
-}
-
-static int finish_stage(blu_hip *h)
-{
-    if (!ensure_out(h, (int64_t)h->hs.lused + h->m, (int64_t)h->hs.uused + h->m)) return BLU_ERROR_OUT_OF_MEMORY;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO);
-    (void)hipEventRecord(h->ev[1], h->stream);
-    if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_finish")) return BLU_ERROR_DEVICE;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-    h->t_total = 1e-3 * ms;
-    if (!download_scalars(h)) return BLU_ERROR_DEVICE;
-    if (h->hs.status != ST_DONE) {
-        char buf[128];
-        snprintf(buf, sizeof buf, "finish failed: device status %d line %d", h->hs.status, h->hs.err_line);
-        h->err = buf;
-        return BLU_ERROR_DEVICE;
-    }
-    // factorization successfully finished (factorize.rs:114-119)
-    h->nupdate = 0;
-    h->nfactorize++;
-    return h->hs.rank < h->m ? BLU_WARNING_SINGULAR_MATRIX : BLU_OK;
-}
-
-static int factorize_device_impl(blu_hip *h, const uint64_t *d_b_begin, const uint64_t *d_b_end,
-                                 const uint64_t *d_b_i, const double *d_b_x, uint64_t b_i_len)
-{
-    DevLU &D = h->D;
-    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
-    h->err.clear();
-    h->nupdate = -1; // lu.reset(): invalidate (lu.rs:331)
-    h->t_pivot = 0;
-    h->t_total = 0;
-    h->relaunches = 0;
-    D.b_begin = (const unsigned long long *)d_b_begin;
-    D.b_end = (const unsigned long long *)d_b_end;
-    D.b_i = (const unsigned long long *)d_b_i;
-    D.b_x = d_b_x;
-    D.b_i_len = (long long)b_i_len;
-    if (h->m == 0) { // nothing to do; the reference would run its loops over empty ranges
-        memset(&h->hs, 0, sizeof(Scalars));
-        h->nupdate = 0;
-        h->nfactorize++;
-        return BLU_OK;
-    }
-    (void)hipEventRecord(h->ev[0], h->stream);
-    for (int attempt = 0; attempt < 64; attempt++) {
-        Scalars z;
-        memset(&z, 0, sizeof z);
-        z.status = ST_RUNNING;
-        z.pivot_row = z.pivot_col = -1;
-        if (!hip_ok(h, hipMemcpy(D.s, &z, sizeof z, hipMemcpyHostToDevice), "scalars reset") || !upload_desc(h)) return BLU_ERROR_DEVICE;
-        hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, h->stream, h->dD);
-        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_prep") || !download_scalars(h)) return BLU_ERROR_DEVICE;
-        int st = h->hs.status;
-        if (st == ST_INVALID_ARG) return BLU_ERROR_INVALID_ARGUMENT;
-        if (st == ST_NEED_CW) { // packed copies of B too small
-            const int64_t n = std::min<int64_t>((int64_t)h->hs.need + 64, kIntMax);
-            dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_idx); dfree(D.bt_val);
-            if (!dalloc(h, &D.bc_idx, n) || !dalloc(h, &D.bc_val, n) || !dalloc(h, &D.bt_idx, n) || !dalloc(h, &D.bt_val, n)) return BLU_ERROR_OUT_OF_MEMORY;
-            D.nzcap = (int)n;
-            continue;
-        }
-        if (st == ST_NEED_L || st == ST_NEED_U) {
-            h->hs.lused = h->hs.uused = 0;
-            if (!(st == ST_NEED_L ? grow_l(h, h->hs.need) : grow_u(h, h->hs.need))) return BLU_ERROR_OUT_OF_MEMORY;
-            continue;
-        }
-        if (st != ST_RUNNING) {
-            char buf[128];
-            snprintf(buf, sizeof buf, "prep failed: device status %d line %d", st, h->hs.err_line);
-            h->err = buf;
-            return BLU_ERROR_DEVICE;
-        }
-        // setup_bump; arenas are grown until the bump fits (setup_bump.rs:105-113)
-        bool again = false;
-        for (int a2 = 0; a2 < 64; a2++) {
-            hipLaunchKernelGGL(k_setup, dim3(1), dim3(1024), 0, h->stream, h->dD);
-            if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_setup") || !download_scalars(h)) return BLU_ERROR_DEVICE;
-            st = h->hs.status;
-            if (st == ST_NEED_CW || st == ST_NEED_RW) {
-                const int64_t n = grown(h, 2 * (int64_t)h->hs.need, 0);
-                if (st == ST_NEED_CW) {
-                    dfree(D.cidx); dfree(D.cval);
-                    if (!dalloc(h, &D.cidx, n) || !dalloc(h, &D.cval, n)) return BLU_ERROR_OUT_OF_MEMORY;
-                    D.carena_cap = (int)n;
-                } else {
-                    dfree(D.ridx);
-                    if (!dalloc(h, &D.ridx, n)) return BLU_ERROR_OUT_OF_MEMORY;
-                    D.rarena_cap = (int)n;
-                }
-                if (!upload_desc(h) || !set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
-                continue;
-            }
-            break;
-        }
-        if (again) continue;
-        if (st != ST_RUNNING) {
-            char buf[128];
-            snprintf(buf, sizeof buf, "setup failed: device status %d line %d", st, h->hs.err_line);
-            h->err = buf;
-            return BLU_ERROR_DEVICE;
-        }
-        return pivot_stage(h);
-    }
-    h->err = "factorize: too many reallocation rounds";
-    return BLU_ERROR_DEVICE;
-}
-
-extern "C" int blu_hip_factorize_device(blu_hip *h, const uint64_t *d_b_begin, const uint64_t *d_b_end,
-                                        const uint64_t *d_b_i, const double *d_b_x, uint64_t b_i_len)
-{
-    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
-    if (h->m > 0 && (!d_b_begin || !d_b_end || (b_i_len && (!d_b_i || !d_b_x)))) return BLU_ERROR_ARGUMENT_MISSING;
-    return factorize_device_impl(h, d_b_begin, d_b_end, d_b_i, d_b_x, b_i_len);
-}
-
-// BLU::factorize with host arrays: copy B to the device, then as above
-extern "C" int blu_hip_factorize(blu_hip *h, const uint64_t *b_begin, const uint64_t *b_end,
-                                 const uint64_t *b_i, const double *b_x, uint64_t b_i_len)
-{
-    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
-    if (h->m > 0 && (!b_begin || !b_end || (b_i_len && (!b_i || !b_x)))) return BLU_ERROR_ARGUMENT_MISSING;
-    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
-    const size_t M = (size_t)h->m, NZ = (size_t)b_i_len;
-    if ((int64_t)M > h->ob_mcap) {
-        dfree(h->ob_begin); dfree(h->ob_end);
-        if (!dalloc(h, &h->ob_begin, M) || !dalloc(h, &h->ob_end, M)) return BLU_ERROR_OUT_OF_MEMORY;
-        h->ob_mcap = (int64_t)M;
-    }
-    if ((int64_t)NZ > h->ob_nzcap) {
-        dfree(h->ob_i); dfree(h->ob_x);
-        if (!dalloc(h, &h->ob_i, NZ) || !dalloc(h, &h->ob_x, NZ)) return BLU_ERROR_OUT_OF_MEMORY;
-        h->ob_nzcap = (int64_t)NZ;
-    }
-    bool ok = true;
-    if (M) ok = ok && hip_ok(h, hipMemcpy(h->ob_begin, b_begin, M * 8, hipMemcpyHostToDevice), "h2d b_begin");
-    if (M) ok = ok && hip_ok(h, hipMemcpy(h->ob_end, b_end, M * 8, hipMemcpyHostToDevice), "h2d b_end");
-    if (NZ) ok = ok && hip_ok(h, hipMemcpy(h->ob_i, b_i, NZ * 8, hipMemcpyHostToDevice), "h2d b_i");
-    if (NZ) ok = ok && hip_ok(h, hipMemcpy(h->ob_x, b_x, NZ * 8, hipMemcpyHostToDevice), "h2d b_x");
-    if (!ok) return BLU_ERROR_DEVICE;
-    return factorize_device_impl(h, (const uint64_t *)h->ob_begin, (const uint64_t *)h->ob_end,
-                                 (const uint64_t *)h->ob_i, h->ob_x, b_i_len);
-}
+#include "blu_driver.inc"
 
 // BLU::get_factors -- src/blu.rs:139, get_factors.rs:48-180
 extern "C" int blu_hip_get_factors(blu_hip *h, int64_t *rowperm, int64_t *colperm,
@@ -641,34 +468,18 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// batch of independent factorizations on one device, one workgroup per handle
-// ---------------------------------------------------------------------------------------------
-extern "C" int blu_hip_factorize_batch(blu_hip **hs, int n, const uint64_t *const *b_begin,
-                                       const uint64_t *const *b_end, const uint64_t *const *b_i,
-                                       const double *const *b_x, const uint64_t *b_i_len,
-                                       int inputs_on_device, int *status)
-{
-    // Round 1: handles are processed through the single-matrix driver on their own streams is NOT
-    // implemented yet; this entry runs them back to back (correct, not concurrent).
-    if (!hs || n < 0) return BLU_ERROR_ARGUMENT_MISSING;
-    int worst = BLU_OK;
-    for (int k = 0; k < n; k++) {
-        int st = inputs_on_device ? blu_hip_factorize_device(hs[k], b_begin[k], b_end[k], b_i[k], b_x[k], b_i_len[k])
-                                  : blu_hip_factorize(hs[k], b_begin[k], b_end[k], b_i[k], b_x[k], b_i_len[k]);
-        if (status) status[k] = st;
-        if (st < 0) worst = st;
-        else if (st > worst && worst >= 0) worst = st;
-    }
-    return worst;
-}
-
-// ---------------------------------------------------------------------------------------------
 // debug / test hooks (step-wise comparison with the oracle); not part of the drop-in surface
 // ---------------------------------------------------------------------------------------------
 extern "C" int blu_hip_dbg_set_stop(blu_hip *h, int64_t stop_at)
 {
     if (!h) return BLU_ERROR_ARGUMENT_MISSING;
     h->stop_at = stop_at;
+    return BLU_OK;
+}
+extern "C" int blu_hip_dbg_set_batch_block(blu_hip *h, int threads)
+{
+    if (!h || threads < 64 || threads > 1024 || (threads & 63)) return BLU_ERROR_INVALID_ARGUMENT;
+    h->batch_block = threads;
     return BLU_OK;
 }
 extern "C" int blu_hip_dbg_set_no_fast(blu_hip *h, int on)
@@ -692,7 +503,7 @@ extern "C" int blu_hip_dbg_continue(blu_hip *h, int64_t stop_at)
     if (!download_scalars(h)) return BLU_ERROR_DEVICE;
     if (h->hs.status != ST_STOPPED) return BLU_ERROR_INVALID_CALL;
     if (!set_status(h, ST_RUNNING)) return BLU_ERROR_DEVICE;
-    return pivot_stage(h);
+    return continue_pivot_single(h);
 }
 template <class T> static bool d2h_vec(blu_hip *h, std::vector<T> &v, const T *d, size_t n)
 {

@@ -32,8 +32,22 @@ __shared__ int g_pivot_err;
 
 #include "k_pivot_fast_types.h"
 
+// Diagnostic build (-DBLU_PROFILE, `make prof`): thread 0 stamps the shader clock at phase boundaries
+// of the pivot loop.  The product build contains no stamps.
+#ifdef BLU_PROFILE
+#define PROF_STAMP(k)                                                      \
+    do {                                                                   \
+        if (threadIdx.x == 0) sm->pstamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PROF_STAMP(k) \
+    do {              \
+    } while (0)
+#endif
+
 struct Sm {
     Fast fa;
+    long long prof[8], pstamp[8];
     int pr, pc;
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
@@ -1176,6 +1190,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->d3 = 0;
         sm->stop_at = stop_at;
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
+        for (int k = 0; k < 8; k++) sm->prof[k] = 0;
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
     if (tid == 0) g_pivot_err = 0;
@@ -1191,6 +1206,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         }
         __syncthreads();
         if (sm->exit_code) break;
+        PROF_STAMP(0);
 
         // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
         // `need_search` is decided by thread 0 before the barrier above: sm->pc itself is rewritten by
@@ -1233,6 +1249,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 
         // ---- pivot(): the room check of pivot.rs:70-81 was made by the searching wave; dispatch (:84-94)
         if (sm->exit_code) break;
+        PROF_STAMP(1);
         const int nz_col = sm->nzc, nz_row = sm->nzr;
         bool ok = true;
         if (sm->fa.kind == 1) fast_small(D, sm);
@@ -1242,6 +1259,16 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
         else ok = pivot_general(D, sm, nz_col - 1 <= 64);
         if (!ok) break; // exit_code set, pivot stays pending
+        PROF_STAMP(2);
+#ifdef BLU_PROFILE
+        if (tid == 0) {
+            const int kk = sm->fa.kind == 1 ? 1 : (sm->fa.kind == 2 ? 2 : 3);
+            sm->prof[0] += sm->pstamp[1] - sm->pstamp[0];  // search + set-up (incl. barrier)
+            sm->prof[kk] += sm->pstamp[2] - sm->pstamp[1]; // pivot: 1 fast small, 2 fast singleton col, 3 general paths
+            sm->prof[3 + kk] += 1;                         // counts at 4,5,6
+            if (kk == 1) sm->prof[7] += sm->pstamp[3] - sm->pstamp[1]; // fast small: line updates (rest = finalize)
+        }
+#endif
 
         // ---- remove columns whose maximum dropped below abstol (pivot.rs:98-106), record the pivot
         if (tid == 0) {
@@ -1281,6 +1308,9 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         S->nexpand += sm->nexpand;
         S->d3_hits += sm->d3;
         for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
+#ifdef BLU_PROFILE
+        for (int k = 0; k < 8; k++) S->prof[k] += sm->prof[k];
+#endif
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }
 }

@@ -621,6 +621,7 @@ __device__ void fast_small(const DevLU &D, Sm *sm)
         else fast_row(D, sm, t - rnz1 + 1);
     }
     __syncthreads();
+    PROF_STAMP(3);
     if (fa->anycancel) {
         for (int p = 1 + w; p <= cnz1; p += nw) fast_fixrow(D, sm, p);
         __syncthreads();

@@ -266,3 +266,47 @@ def test_generators_agree(blu, oracle):
         b = oracle.gen_lp_basis(*args)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_batch_of_independent_bases(blu, oracle):
+    """blu_hip_factorize_batch: one workgroup per handle, all kernels launched once for the batch.
+    Mixed sizes, one singular and one invalid member; every member must equal its own oracle run."""
+    specs = [(300, 5, 4, 0.5, 1, 0.3), (1200, 8, 8, 0.5, 2, 0.3), (50, 4, 3, 0.5, 3, 0.3), (2000, 8, 8, 0.5, 4, 0.3),
+             (700, 6, 6, 1.0, 5, 0.2), (900, 7, 8, 0.5, 21, 0.4), (400, 6, 6, 0.0, 13, 0.5), (1500, 8, 16, 0.2, 3, 1.0)]
+    mats = [list(oracle.gen_lp_basis(*s)) for s in specs]
+    mats[5][2] = mats[5][2].copy()
+    for j in (3, 77, 500, 899):  # singular member
+        mats[5][2][int(mats[5][0][j]):int(mats[5][0][j + 1])] *= 1e-17
+    mats[2][1] = mats[2][1].copy()
+    mats[2][1][5] = 50  # invalid member: row index out of range
+    hs = [blu.BLU(len(m[0]) - 1, len(m[1]) if k != 7 else 16) for k, m in enumerate(mats)]  # member 7 starts far too small
+    for block in (256, 64, 1024):
+        sts = blu.blu.factorize_batch(hs, mats=[tuple(m) for m in mats], block=block)
+        for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
+            o = oracle.OracleBLU(len(cp) - 1, 64 * len(ri))
+            o.set_fix_d3(True)
+            so = o.factorize(cp[:-1], cp[1:], ri, v)
+            assert sts[k] == so, (k, sts[k], so)
+            if so in (K.OK, K.WARNING_SINGULAR_MATRIX):
+                util.assert_same_factors(h.get_factors(), o.get_factors())
+                for c in util.COUNTERS:
+                    assert int(h.stat(getattr(K, "STAT_" + c))) == int(o.stat(getattr(K, "STAT_" + c))), (k, c)
+        assert sts[2] == K.ERROR_INVALID_ARGUMENT and sts[5] == K.WARNING_SINGULAR_MATRIX
+    # handles stay usable one by one after a batch, and solves work off batch results
+    cp, ri, v = mats[1]
+    B = util.csc(cp, ri, v, len(cp) - 1)
+    xs = np.random.default_rng(0).standard_normal(len(cp) - 1)
+    np.testing.assert_allclose(hs[1].solve_dense(B @ xs), xs, rtol=1e-7, atol=1e-9)
+    assert hs[0].factorize(mats[0][0][:-1], mats[0][0][1:], mats[0][1], mats[0][2]) == K.OK
+
+
+def test_general_paths_only_matches_fast_paths(blu, oracle):
+    """A/B of the two implementations of the pivot loop (LDS fast paths on / off)."""
+    cp, ri, v = oracle.gen_lp_basis(3000, 9, 10, 0.4, 17, 0.4)
+    a, b = blu.BLU(3000, len(ri)), blu.BLU(3000, len(ri))
+    b.dbg_set_no_fast(True)
+    assert a.factorize(cp[:-1], cp[1:], ri, v) == b.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    fa, fb = a.get_factors(), b.get_factors()
+    for k in util.INT_KEYS + util.VAL_KEYS:
+        assert np.array_equal(fa[k], fb[k]), k
+    assert a.stat(54) > 0 and a.stat(K.STAT_NSEARCH_PIVOT) == b.stat(K.STAT_NSEARCH_PIVOT)

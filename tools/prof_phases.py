@@ -1,0 +1,24 @@
+"""Phase breakdown of the pivot loop from the diagnostic build (make -C blu_amd/csrc prof).
+   BLU_HIP_LIB=blu_amd/libblu_hip_prof.so python tools/prof_phases.py [C2|C3] [block]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blu_amd
+from blu_amd import keys as K
+from blu_amd.matrices import CONFIGS
+c = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C2"]
+cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+h = blu_amd.BLU(c["m"], len(ri))
+if len(sys.argv) > 2:
+    h.dbg_set_block(int(sys.argv[2]))
+for rep in range(2):
+    st = h.factorize(cp[:-1], cp[1:], ri, v)
+p = [h.stat(60 + k) for k in range(8)]
+tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
+tot = sum(p[:4])
+print("status", st, "t_pivot %.1f ms" % (1e3 * tp), "ticks total %.3g -> %.2f GHz-equivalent" % (tot, tot / tp / 1e9))
+n1, n2, n3 = p[4], p[5], p[6]
+f = tp / tot * 1e6  # us per tick
+print("search+setup: %.2f us/pivot (%.0f%%)" % (p[0] * f / max(1, n1 + n2 + n3), 100 * p[0] / tot))
+print("fast small  : n=%d %.2f us each (%.0f%%), of which line updates %.2f us" % (n1, p[1] * f / max(1, n1), 100 * p[1] / tot, p[7] * f / max(1, n1)))
+print("fast scol   : n=%d %.2f us each (%.0f%%)" % (n2, p[2] * f / max(1, n2), 100 * p[2] / tot))
+print("general     : n=%d %.2f us each (%.0f%%)" % (n3, p[3] * f / max(1, n3), 100 * p[3] / tot))
