@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <rocprim/warp/warp_reduce.hpp>
 
 #define BLU_WAVE 64
 
@@ -58,64 +59,99 @@ struct Scalars {
     double min_pivot, max_pivot;
     double onenorm, infnorm;
     double norm_l, norm_u, normest_l_inv, normest_u_inv, condest_l, condest_u, residual_test;
-    long long prof[8];    // diagnostic build only (-DBLU_PROFILE): shader-clock ticks per phase of the pivot loop
+    long long prof[16];    // diagnostic build only (-DBLU_PROFILE): shader-clock ticks per phase of the pivot loop
 };
 
+// Scalar members of the descriptor: dimensions, parameters (public fields of struct LU,
+// src/lu/lu.rs:11-66) and capacities.
+#define DEVLU_SCALARS(X)                                                                               \
+    X(int, m)                                                                                          \
+    X(int, nzbias)      /* -1 = None */                                                                \
+    X(int, maxsearch)                                                                                  \
+    X(int, pad)                                                                                        \
+    X(int, search_rows)                                                                                \
+    X(int, no_fast)     /* debug: 1 = general pivot paths only (k_pivot_fast.hip off) */               \
+    X(double, droptol)                                                                                 \
+    X(double, abstol)                                                                                  \
+    X(double, reltol)                                                                                  \
+    X(double, stretch)                                                                                 \
+    X(long long, b_i_len)                                                                              \
+    X(int, nzcap)                                                                                      \
+    X(int, carena_cap)                                                                                 \
+    X(int, rarena_cap)                                                                                 \
+    X(int, lcap)                                                                                       \
+    X(int, ucap)
+
+// Array members (all in HBM):
+//   b_*            input matrix as handed over by the caller (device copies of the uint64 arrays)
+//   bc_*, bt_*     packed B: columnwise and rowwise-sorted-by-column
+//   pinv,qinv      inverse permutations (-1 = not pivoted); prow,pcol = pivot row / column of stage k
+//   cbeg..cval     column file (index + value), rbeg..ridx row file (index only); colmax = col_pivot
+//   c/r f/blink    count lists, same representation as src/lu/list.rs (heads at m+nz), 2m+2 entries
+//   rowmark,colmark,iw2   all-zero scratch of the general pivot paths
+//   tnew,tnewr,txrj,tmask per pivot-row column / pivot-column row results of the general pivot paths
+//   gwork          16 * (m+1) doubles: pivot_any dense work columns
+//   iw0,iw1        m+2 ints each: prep / finish scratch
+//   lbeg..uval     factors in stage order: L column k = lidx/lval[lbeg[k]..lbeg[k+1]), U row k likewise
+#define DEVLU_ARRAYS(X)                                                                                \
+    X(const unsigned long long, b_begin) X(const unsigned long long, b_end) X(const unsigned long long, b_i) \
+    X(const double, b_x)                                                                               \
+    X(int, bc_ptr) X(int, bc_idx) X(double, bc_val) X(int, bt_ptr) X(int, bt_idx) X(double, bt_val)    \
+    X(int, pinv) X(int, qinv) X(int, prow) X(int, pcol)                                                \
+    X(int, cbeg) X(int, clen) X(int, ccap) X(int, cidx) X(double, cval)                                \
+    X(int, rbeg) X(int, rlen) X(int, rcap) X(int, ridx) X(double, colmax)                              \
+    X(int, cflink) X(int, cblink) X(int, rflink) X(int, rblink)                                        \
+    X(int, rowmark) X(int, colmark) X(int, tnew) X(int, tnewr) X(double, txrj)                         \
+    X(unsigned long long, tmask) X(double, gwork) X(int, iw0) X(int, iw1) X(int, iw2)                  \
+    X(int, lbeg) X(int, ubeg) X(int, lidx) X(int, uidx) X(double, lval) X(double, uval)
+
+// The descriptor as the host fills it and as it lives in HBM: plain (generic) pointers.
 struct DevLU {
-    // dimensions and parameters (public fields of struct LU, src/lu/lu.rs:11-66)
-    int m;
-    int nzbias;           // -1 = None
-    int maxsearch;
-    int pad;
-    int search_rows;
-    int no_fast;          // debug: 1 = general pivot paths only (k_pivot_fast.hip off)
-    double droptol, abstol, reltol, stretch;
-
-    // input matrix as handed over by the caller (device copies of the uint64 arrays)
-    const unsigned long long *b_begin, *b_end, *b_i;
-    const double *b_x;
-    long long b_i_len;
-
-    // packed B: columnwise (bc_*) and rowwise sorted by column (bt_*)
-    int *bc_ptr, *bc_idx;
-    double *bc_val;
-    int *bt_ptr, *bt_idx;
-    double *bt_val;
-    int nzcap;
-
-    // pivot sequence
-    int *pinv, *qinv;     // inverse permutations (-1 = not pivoted)
-    int *prow, *pcol;     // pivot row / column of stage k
-
-    // active submatrix: column file (index+value), row file (index only)
-    int *cbeg, *clen, *ccap;
-    int *cidx;
-    double *cval;
-    int carena_cap;
-    int *rbeg, *rlen, *rcap;
-    int *ridx;
-    int rarena_cap;
-    double *colmax;       // col_pivot in the reference: column maximum, later the pivot
-
-    // count lists, same representation as src/lu/list.rs (heads at m+nz), 2m+2 entries
-    int *cflink, *cblink, *rflink, *rblink;
-
-    // scratch, all-zero between pivots
-    int *rowmark, *colmark;
-    int *tnew;            // per pivot-row column: new column count
-    int *tnewr;           // per pivot-column row: new row count
-    double *txrj;         // per pivot-row column: pivot-row entry
-    unsigned long long *tmask; // per pivot-row column: cancellation mask (pivot_small)
-    double *gwork;        // nwaves * (m+1) doubles: pivot_any dense work columns
-    int *iw0, *iw1, *iw2; // m+2 ints each: prep/finish scratch
-
-    // factors, stage order: L column k = lidx/lval[lbeg[k]..lbeg[k+1]), U row k likewise
-    int *lbeg, *ubeg;     // m+1
-    int *lidx, *uidx;
-    double *lval, *uval;
-    int lcap, ucap;
-
+#define X(T, n) T n;
+    DEVLU_SCALARS(X)
+#undef X
+#define X(T, n) T *n;
+    DEVLU_ARRAYS(X)
+#undef X
     Scalars *s;
+};
+
+// The same descriptor as the kernels use it: every array pointer typed as GLOBAL address space.
+// A pointer loaded from a struct in memory is a generic ("flat") pointer to the compiler, and every
+// access through it becomes flat_load / flat_store, which are slower than global_* and tie the LDS
+// and vector-memory wait counters together.  Kernels build a DevG from their DevLU once.
+#define GPTR(T) __attribute__((address_space(1))) T *
+typedef GPTR(int) gint_p;
+typedef GPTR(const int) gcint_p;
+typedef GPTR(double) gdouble_p;
+// atomics on global-address-space pointers (the HIP atomicAdd/atomicMin overloads take generic pointers)
+__device__ __forceinline__ int g_atomic_add(gint_p p, int v)
+{
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int g_atomic_min(gint_p p, int v)
+{
+    return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct DevG {
+#define X(T, n) T n;
+    DEVLU_SCALARS(X)
+#undef X
+#define X(T, n) GPTR(T) n;
+    DEVLU_ARRAYS(X)
+#undef X
+    Scalars *s;
+    __device__ __forceinline__ explicit DevG(const DevLU &d)
+        :
+#define X(T, n) n(d.n),
+          DEVLU_SCALARS(X)
+#undef X
+#define X(T, n) n((GPTR(T))d.n),
+              DEVLU_ARRAYS(X)
+#undef X
+                  s(d.s)
+    {
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -131,49 +167,31 @@ __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1u
 // and is a compiler barrier.  Needed where one lane's store feeds another lane's later load.
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ long long wave_min_ll(long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        long long t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ long long wave_sum_ll(long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// Wave-wide all-reductions through rocPRIM's DPP implementation (row_shr / row_bcast data-parallel
+// primitives: ~6 VALU ops per 32-bit word) instead of __shfl_xor butterflies, which compile to
+// ds_bpermute (an LDS-crossbar round trip per step) -- measured 3-4x cheaper on the pivot loop's
+// critical path.  Every lane receives the result.
+struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpSumI { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+struct OpMinLL { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a < b ? a : b; } };
+struct OpSumLL { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a + b; } };
 // max of non-negative doubles (|x| values): plain compare, NaN never selected (matches `if x > cmx`)
-__device__ __forceinline__ double wave_max_d(double v)
+struct OpMaxD { __device__ __forceinline__ double operator()(double a, double b) const { return b > a ? b : a; } };
+template <class T, class Op> __device__ __forceinline__ T wave_allreduce(T v, Op op)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
+    using WR = rocprim::warp_reduce<T, 64, true>;
+    typename WR::storage_type st; // empty for the DPP implementation
+    T out;
+    WR().reduce(v, out, st, op);
+    return out;
 }
+__device__ __forceinline__ int wave_min_i(int v) { return wave_allreduce(v, OpMinI()); }
+__device__ __forceinline__ int wave_max_i(int v) { return wave_allreduce(v, OpMaxI()); }
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_allreduce(v, OpSumI()); }
+__device__ __forceinline__ long long wave_min_ll(long long v) { return wave_allreduce(v, OpMinLL()); }
+__device__ __forceinline__ long long wave_sum_ll(long long v) { return wave_allreduce(v, OpSumLL()); }
+__device__ __forceinline__ double wave_max_d(double v) { return wave_allreduce(v, OpMaxD()); }
 // inclusive scan over the wave
 __device__ __forceinline__ int wave_incl_scan_i(int v)
 {

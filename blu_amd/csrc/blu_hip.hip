@@ -33,6 +33,7 @@ struct blu_hip {
     int64_t nupdate;   // -1 = None
     int64_t nfactorize;
     DevLU D;           // host copy of the device descriptor (device pointers inside)
+    char *slab;        // one allocation holding every fixed-size device array of this handle
     DevLU *dD;         // device copy (own slot)
     DevLU *dslot;      // where the descriptor currently lives on the device: dD, or a slot of a batch array
     Scalars hs;        // last downloaded scalars
@@ -99,20 +100,14 @@ static const int64_t kIntMax = 0x7ffffff0;
 static void free_all(blu_hip *h)
 {
     DevLU &D = h->D;
-    dfree(D.bc_ptr); dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_ptr); dfree(D.bt_idx); dfree(D.bt_val);
-    dfree(D.pinv); dfree(D.qinv); dfree(D.prow); dfree(D.pcol);
-    dfree(D.cbeg); dfree(D.clen); dfree(D.ccap); dfree(D.cidx); dfree(D.cval);
-    dfree(D.rbeg); dfree(D.rlen); dfree(D.rcap); dfree(D.ridx); dfree(D.colmax);
-    dfree(D.cflink); dfree(D.cblink); dfree(D.rflink); dfree(D.rblink);
-    dfree(D.rowmark); dfree(D.colmark); dfree(D.tnew); dfree(D.tnewr); dfree(D.txrj); dfree(D.tmask);
-    dfree(D.gwork); dfree(D.iw0); dfree(D.iw1); dfree(D.iw2);
-    dfree(D.lbeg); dfree(D.ubeg); dfree(D.lidx); dfree(D.uidx); dfree(D.lval); dfree(D.uval);
-    dfree(D.s);
-    dfree(h->dD); dfree(h->dO);
-    dfree(h->O.rowperm); dfree(h->O.colperm); dfree(h->O.l_colptr); dfree(h->O.l_rowidx); dfree(h->O.l_value);
-    dfree(h->O.u_colptr); dfree(h->O.u_rowidx); dfree(h->O.u_value);
+    // growable storage: separate allocations
+    dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_idx); dfree(D.bt_val);
+    dfree(D.cidx); dfree(D.cval); dfree(D.ridx);
+    dfree(D.lidx); dfree(D.uidx); dfree(D.lval); dfree(D.uval);
+    dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value);
     dfree(h->ob_begin); dfree(h->ob_end); dfree(h->ob_i); dfree(h->ob_x);
-    dfree(h->d_rhs); dfree(h->d_lhs); dfree(h->lvl_l); dfree(h->lvl_u);
+    // everything else lives in the slab
+    dfree(h->slab);
 }
 
 static bool upload_desc(blu_hip *h)
@@ -190,24 +185,35 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     D.carena_cap = (int)std::min<int64_t>(6 * b_nz + 8 * m + 64, kIntMax);
     D.rarena_cap = D.carena_cap;
     bool ok = true;
-    ok = ok && dalloc(h, &D.bc_ptr, M + 1) && dalloc(h, &D.bc_idx, D.nzcap) && dalloc(h, &D.bc_val, D.nzcap);
-    ok = ok && dalloc(h, &D.bt_ptr, M + 1) && dalloc(h, &D.bt_idx, D.nzcap) && dalloc(h, &D.bt_val, D.nzcap);
-    ok = ok && dalloc(h, &D.pinv, M) && dalloc(h, &D.qinv, M) && dalloc(h, &D.prow, M + 1) && dalloc(h, &D.pcol, M + 1);
-    ok = ok && dalloc(h, &D.cbeg, M) && dalloc(h, &D.clen, M) && dalloc(h, &D.ccap, M);
-    ok = ok && dalloc(h, &D.cidx, D.carena_cap) && dalloc(h, &D.cval, D.carena_cap);
-    ok = ok && dalloc(h, &D.rbeg, M) && dalloc(h, &D.rlen, M) && dalloc(h, &D.rcap, M) && dalloc(h, &D.ridx, D.rarena_cap);
-    ok = ok && dalloc(h, &D.colmax, M);
-    ok = ok && dalloc(h, &D.cflink, 2 * M + 2) && dalloc(h, &D.cblink, 2 * M + 2);
-    ok = ok && dalloc(h, &D.rflink, 2 * M + 2) && dalloc(h, &D.rblink, 2 * M + 2);
-    ok = ok && dalloc(h, &D.rowmark, M) && dalloc(h, &D.colmark, M);
-    ok = ok && dalloc(h, &D.tnew, M + 2) && dalloc(h, &D.tnewr, M + 2) && dalloc(h, &D.txrj, M + 2) && dalloc(h, &D.tmask, M + 2);
-    ok = ok && dalloc(h, &D.gwork, 16 * (M + 1));
-    ok = ok && dalloc(h, &D.iw0, M + 2) && dalloc(h, &D.iw1, M + 2) && dalloc(h, &D.iw2, M + 2);
-    ok = ok && dalloc(h, &D.lbeg, M + 1) && dalloc(h, &D.ubeg, M + 1);
+    // Every fixed-size (m-dependent) array lives in ONE allocation: the pivot loop hops randomly over
+    // all of them, and one large hipMalloc is mapped with large page-table fragments, while ~35
+    // separate sub-megabyte allocations are not (TLB reach).  Growable storage stays separate.
+    size_t slab_bytes = 0;
+    std::vector<std::pair<void **, size_t>> reqs;
+    auto want = [&](auto **p, size_t n) {
+        reqs.push_back({(void **)p, slab_bytes});
+        slab_bytes += (std::max<size_t>(n, 1) * sizeof(**p) + 255) & ~(size_t)255;
+    };
+    want(&D.bc_ptr, M + 1); want(&D.bt_ptr, M + 1);
+    want(&D.pinv, M); want(&D.qinv, M); want(&D.prow, M + 1); want(&D.pcol, M + 1);
+    want(&D.cbeg, M); want(&D.clen, M); want(&D.ccap, M);
+    want(&D.rbeg, M); want(&D.rlen, M); want(&D.rcap, M);
+    want(&D.colmax, M);
+    want(&D.cflink, 2 * M + 2); want(&D.cblink, 2 * M + 2); want(&D.rflink, 2 * M + 2); want(&D.rblink, 2 * M + 2);
+    want(&D.rowmark, M); want(&D.colmark, M);
+    want(&D.tnew, M + 2); want(&D.tnewr, M + 2); want(&D.txrj, M + 2); want(&D.tmask, M + 2);
+    want(&D.gwork, 16 * (M + 1));
+    want(&D.iw0, M + 2); want(&D.iw1, M + 2); want(&D.iw2, M + 2);
+    want(&D.lbeg, M + 1); want(&D.ubeg, M + 1);
+    want(&D.s, 1); want(&h->dD, 1); want(&h->dO, 1);
+    want(&h->O.rowperm, M); want(&h->O.colperm, M); want(&h->O.l_colptr, M + 1); want(&h->O.u_colptr, M + 1);
+    want(&h->d_rhs, M); want(&h->d_lhs, M); want(&h->lvl_l, M + 2); want(&h->lvl_u, M + 2);
+    ok = ok && dalloc(h, &h->slab, slab_bytes);
+    if (ok)
+        for (auto &r : reqs) *r.first = (void *)(h->slab + r.second);
+    ok = ok && dalloc(h, &D.bc_idx, D.nzcap) && dalloc(h, &D.bc_val, D.nzcap) && dalloc(h, &D.bt_idx, D.nzcap) && dalloc(h, &D.bt_val, D.nzcap);
+    ok = ok && dalloc(h, &D.cidx, D.carena_cap) && dalloc(h, &D.cval, D.carena_cap) && dalloc(h, &D.ridx, D.rarena_cap);
     ok = ok && dalloc(h, &D.lidx, D.lcap) && dalloc(h, &D.lval, D.lcap) && dalloc(h, &D.uidx, D.ucap) && dalloc(h, &D.uval, D.ucap);
-    ok = ok && dalloc(h, &D.s, 1) && dalloc(h, &h->dD, 1) && dalloc(h, &h->dO, 1);
-    ok = ok && dalloc(h, &h->O.rowperm, M) && dalloc(h, &h->O.colperm, M) && dalloc(h, &h->O.l_colptr, M + 1) && dalloc(h, &h->O.u_colptr, M + 1);
-    ok = ok && dalloc(h, &h->d_rhs, M) && dalloc(h, &h->d_lhs, M) && dalloc(h, &h->lvl_l, M + 2) && dalloc(h, &h->lvl_u, M + 2);
     if (ok) ok = hip_ok(h, hipMemset(D.gwork, 0, 16 * (M + 1) * sizeof(double)), "hipMemset");
     h->dslot = h->dD;
     h->oslot = h->dO;
@@ -323,7 +329,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 56: return (double)s.npivot_kind[5];
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
-    case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67:
+    case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:
         return (double)s.prof[key - 60]; // diagnostic build only
     default: return NAN;
     }

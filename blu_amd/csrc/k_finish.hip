@@ -91,7 +91,7 @@ __device__ void block_sort_segment(long long *key, double *val, int b, int e, in
 
 __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     const FinishOut &O = Os[blockIdx.x];
     Scalars *S = D.s;
     __shared__ int sh[40];
@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
 
     // ---- complete the permutations: unpivoted rows / columns in index order (build_factors.rs:192-209)
     for (int pass = 0; pass < 2; pass++) {
-        int *inv = pass == 0 ? D.pinv : D.qinv;
-        int *seq = pass == 0 ? D.prow : D.pcol;
+        gint_p inv = pass == 0 ? D.pinv : D.qinv;
+        gint_p seq = pass == 0 ? D.prow : D.pcol;
         int base = rank;
         for (int c0 = 0; c0 < m; c0 += nt) {
             const int e = c0 + tid;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = D.lbeg[k] + k + 1, e = D.lbeg[k + 1] + k + 1;
-            block_sort_segment(O.l_rowidx, O.l_value, b, e, m, D.iw0, D.iw1, D.tnew, D.txrj, sh);
+            block_sort_segment(O.l_rowidx, O.l_value, b, e, m, (int *)D.iw0, (int *)D.iw1, (int *)D.tnew, (double *)D.txrj, sh);
         }
     }
 
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
     for (int k = tid; k < rank; k += nt)
         for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
             const int c = D.qinv[D.uidx[p]];
-            if (c < rank) atomicAdd(&D.iw0[c], 1);
+            if (c < rank) g_atomic_add(&D.iw0[c], 1);
         }
     __syncthreads();
     int base = 0;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
             const int c = D.qinv[D.uidx[p]];
             if (c < rank) {
-                const int pos = atomicAdd(&D.iw1[c], 1);
+                const int pos = g_atomic_add(&D.iw1[c], 1);
                 O.u_rowidx[pos] = k;
                 O.u_value[pos] = D.uval[p];
             }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = (int)O.u_colptr[k];
-            block_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], m, D.iw1, D.tnewr, D.tnew, D.txrj, sh);
+            block_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], m, (int *)D.iw1, (int *)D.tnewr, (int *)D.tnew, (double *)D.txrj, sh);
         }
     }
     // min / max pivot (build_factors.rs:403-419)
@@ -262,13 +262,13 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
 __global__ void __launch_bounds__(1024) k_compact(DevLU *Ds, int which, int *const *new_idx, double *const *new_val,
                                                   const int *new_cap)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ int sh[40];
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
-    int *beg = which ? D.rbeg : D.cbeg, *len = which ? D.rlen : D.clen, *cap = which ? D.rcap : D.ccap;
-    const int *old_idx = which ? D.ridx : D.cidx;
+    gint_p beg = which ? D.rbeg : D.cbeg, len = which ? D.rlen : D.clen, cap = which ? D.rcap : D.ccap;
+    gcint_p old_idx = which ? D.ridx : D.cidx;
     int *nidx = new_idx[blockIdx.x];
     double *nval = which ? nullptr : new_val[blockIdx.x];
     // new offsets; lines that hold nothing get no room (they are dead: pivoted or emptied)

@@ -47,7 +47,7 @@ __shared__ int g_pivot_err;
 
 struct Sm {
     Fast fa;
-    long long prof[8], pstamp[8];
+    long long prof[16], pstamp[16];
     int pr, pc;
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
@@ -67,7 +67,7 @@ struct Sm {
 // ------------------------------------------------------------------------------------------------
 // list primitives (src/lu/list.rs), single-lane versions
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void list_remove1(int *flink, int *blink, int e)
+__device__ __forceinline__ void list_remove1(gint_p flink, gint_p blink, int e)
 {
     const int f = flink[e], b = blink[e];
     flink[b] = f;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void list_remove1(int *flink, int *blink, int e)
     flink[e] = e;
     blink[e] = e;
 }
-__device__ __forceinline__ void list_add1(int e, int list, int *flink, int *blink, int nelem)
+__device__ __forceinline__ void list_add1(int e, int list, gint_p flink, gint_p blink, int nelem)
 {
     const int t = blink[nelem + list];
     blink[nelem + list] = e;
@@ -91,8 +91,8 @@ __device__ __forceinline__ void list_add1(int e, int list, int *flink, int *blin
 // elem(q) / key(q) are read through the two arrays with the given offsets; key < 0 = not moved.
 // `mark` is an all-zero int[m] scratch (restored to zero).  Returns min key > 0 (or big).
 // ------------------------------------------------------------------------------------------------
-__device__ int wave_list_move_batch(int *flink, int *blink, int nelem, const int *elems, const int *keys, int n,
-                                    int *mark, int big)
+__device__ __forceinline__ int wave_list_move_batch(gint_p flink, gint_p blink, int nelem, gcint_p elems, gcint_p keys, int n,
+                                                    gint_p mark, int big)
 {
     const int lane = lane_id();
     int minkey = big;
@@ -151,7 +151,7 @@ __device__ int wave_list_move_batch(int *flink, int *blink, int nelem, const int
 }
 
 // position of `key` in idx[beg .. beg+len) or -1; all lanes of the wave return the same value
-__device__ __forceinline__ int wave_find(const int *idx, int beg, int len, int key)
+__device__ __forceinline__ int wave_find(gcint_p idx, int beg, int len, int key)
 {
     const int lane = lane_id();
     for (int c = 0; c < len; c += 64) {
@@ -167,7 +167,12 @@ __device__ __forceinline__ int wave_find(const int *idx, int beg, int len, int k
 // Markowitz search, columns only (search_rows == 0, the reference default lu.rs:259), ONE wave.
 // markowitz.rs:34-123, done() :195-219.
 // ------------------------------------------------------------------------------------------------
-__device__ void markowitz_wave(const DevLU &D, Sm *sm)
+// COLD marks the general (rarely taken) paths.  They are still inlined: measured on MI355X, keeping
+// them out of line (__noinline__) shrinks the kernel from 106 KB to 27 KB of code but makes the loop
+// 15 % SLOWER -- the calls force the ~50 descriptor pointers and the live state through scratch
+// (156 scratch_load in the loop) -- so the instruction-cache footprint is the lesser evil.
+#define COLD __forceinline__
+__device__ COLD void markowitz_wave(const DevG &D, Sm *sm)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -254,7 +259,7 @@ __device__ void markowitz_wave(const DevLU &D, Sm *sm)
 
 // Markowitz search with row search enabled (search_rows != 0): verbatim single-lane restatement of
 // markowitz.rs:34-193.  Not the default; kept simple.
-__device__ void markowitz_serial(const DevLU &D, Sm *sm)
+__device__ COLD void markowitz_serial(const DevG &D, Sm *sm)
 {
     const int m = D.m;
     Scalars *S = D.s;
@@ -369,7 +374,7 @@ __device__ void markowitz_serial(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // remove_col (pivot.rs:1333-1381): verbatim, one lane (rare: a column maximum fell below abstol)
 // ------------------------------------------------------------------------------------------------
-__device__ void remove_col_serial(const DevLU &D, Sm *sm, int j)
+__device__ COLD void remove_col_serial(const DevG &D, Sm *sm, int j)
 {
     const int m = D.m;
     const int cbeg = D.cbeg[j], cend = cbeg + D.clen[j];
@@ -397,7 +402,7 @@ __device__ void remove_col_serial(const DevLU &D, Sm *sm, int j)
 // pivot_any / pivot_small: one target column per wave (pivot.rs:219-331 / :566-691)
 // q = position of the column in the pivot row (>= 1), work = this wave's dense work column
 // ------------------------------------------------------------------------------------------------
-__device__ void gen_update_col(const DevLU &D, Sm *sm, int q, bool small, double *work)
+__device__ __forceinline__ void gen_update_col(const DevG &D, Sm *sm, int q, bool small, double *work)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -542,7 +547,7 @@ __device__ void gen_update_col(const DevLU &D, Sm *sm, int q, bool small, double
 }
 
 // one target row per wave (pivot.rs:335-398 / :704-771); p = position in the pivot column (>= 1)
-__device__ void gen_update_row(const DevLU &D, Sm *sm, int p, bool small)
+__device__ __forceinline__ void gen_update_row(const DevG &D, Sm *sm, int p, bool small)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -605,7 +610,7 @@ __device__ void gen_update_row(const DevLU &D, Sm *sm, int p, bool small)
 
 // U row of this stage: pivot-row entries with |xrj| > droptol in pivot-row order (pivot.rs:306-312),
 // ONE wave.  elems = pivot row line, positions q0..q1 (inclusive), txrj[q] = value, skipq = position to skip.
-__device__ void wave_write_u(const DevLU &D, Sm *sm, int q0, int q1, int skipq)
+__device__ __forceinline__ void wave_write_u(const DevG &D, Sm *sm, int q0, int q1, int skipq)
 {
     const int lane = lane_id();
     int put = sm->uused;
@@ -630,7 +635,7 @@ __device__ void wave_write_u(const DevLU &D, Sm *sm, int q0, int q1, int skipq)
 
 // L column of this stage: x = val / pivot for the pivot-column entries p0..p1 except skipp, kept if
 // |x| > droptol (pivot.rs:404-416).  ONE wave.
-__device__ void wave_write_l(const DevLU &D, Sm *sm, int p0, int p1, int skipp)
+__device__ __forceinline__ void wave_write_l(const DevG &D, Sm *sm, int p0, int p1, int skipp)
 {
     const int lane = lane_id();
     int put = sm->lused;
@@ -657,7 +662,7 @@ __device__ void wave_write_l(const DevLU &D, Sm *sm, int p0, int p1, int skipp)
 // ------------------------------------------------------------------------------------------------
 // pivot_any / pivot_small, whole workgroup.  Returns false if the kernel must exit (NEED_*).
 // ------------------------------------------------------------------------------------------------
-__device__ bool pivot_general(const DevLU &D, Sm *sm, bool small)
+__device__ COLD bool pivot_general(const DevG &D, Sm *sm, bool small)
 {
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -731,7 +736,7 @@ __device__ bool pivot_general(const DevLU &D, Sm *sm, bool small)
     __syncthreads();
 
     // column file update
-    double *work = small ? &sm->swork[w * 64] : &D.gwork[(size_t)w * (m + 1)];
+    double *work = small ? &sm->swork[w * 64] : (double *)&D.gwork[(size_t)w * (m + 1)];
     for (int q = 1 + w; q <= rnz1; q += nw) gen_update_col(D, sm, q, small, work);
     __syncthreads();
 
@@ -769,7 +774,7 @@ __device__ bool pivot_general(const DevLU &D, Sm *sm, bool small)
 // ------------------------------------------------------------------------------------------------
 // pivot_singleton_row (pivot.rs:835-926)
 // ------------------------------------------------------------------------------------------------
-__device__ bool pivot_singleton_row(const DevLU &D, Sm *sm)
+__device__ COLD bool pivot_singleton_row(const DevG &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -829,7 +834,7 @@ __device__ bool pivot_singleton_row(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // pivot_singleton_col (pivot.rs:928-1025)
 // ------------------------------------------------------------------------------------------------
-__device__ bool pivot_singleton_col(const DevLU &D, Sm *sm)
+__device__ COLD bool pivot_singleton_col(const DevG &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -907,7 +912,7 @@ __device__ bool pivot_singleton_col(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // pivot_doubleton_col (pivot.rs:1027-1331)
 // ------------------------------------------------------------------------------------------------
-__device__ bool pivot_doubleton_col(const DevLU &D, Sm *sm)
+__device__ COLD bool pivot_doubleton_col(const DevG &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1138,7 +1143,7 @@ __device__ bool pivot_doubleton_col(const DevLU &D, Sm *sm)
 
 // set-up of a pivot for the general paths (after the general searches, or for a pivot that was
 // pending when the kernel left with NEED_*): line positions and the L/U room check of pivot.rs:70-81
-__device__ void setup_pivot_general(const DevLU &D, Sm *sm)
+__device__ COLD void setup_pivot_general(const DevG &D, Sm *sm)
 {
     Scalars *S = D.s;
     const int pr = sm->pr, pc = sm->pc;
@@ -1163,7 +1168,7 @@ __device__ void setup_pivot_general(const DevLU &D, Sm *sm)
 
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ Sm smem;
     Sm *sm = &smem;
@@ -1190,7 +1195,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->d3 = 0;
         sm->stop_at = stop_at;
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
-        for (int k = 0; k < 8; k++) sm->prof[k] = 0;
+        for (int k = 0; k < 16; k++) sm->prof[k] = 0;
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
     if (tid == 0) g_pivot_err = 0;
@@ -1266,7 +1271,19 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             sm->prof[0] += sm->pstamp[1] - sm->pstamp[0];  // search + set-up (incl. barrier)
             sm->prof[kk] += sm->pstamp[2] - sm->pstamp[1]; // pivot: 1 fast small, 2 fast singleton col, 3 general paths
             sm->prof[3 + kk] += 1;                         // counts at 4,5,6
-            if (kk == 1) sm->prof[7] += sm->pstamp[3] - sm->pstamp[1]; // fast small: line updates (rest = finalize)
+            if (kk == 1) {
+                sm->prof[7] += sm->pstamp[3] - sm->pstamp[1];   // fast small: line updates (rest = finalize)
+            }
+            if (kk != 3) { // stages of the flattened search (stamps 8..14 set inside markowitz_fast)
+                sm->prof[8] += sm->pstamp[8] - sm->pstamp[0];   // head barrier -> search entered
+                sm->prof[9] += sm->pstamp[9] - sm->pstamp[8];   // walk: list heads + K link/meta loads
+                sm->prof[10] += sm->pstamp[10] - sm->pstamp[9]; // candidate entries + row metadata, costs
+                sm->prof[11] += sm->pstamp[11] - sm->pstamp[10]; // argmin
+                sm->prof[12] += sm->pstamp[12] - sm->pstamp[11]; // pivot column to LDS + pivot row load
+                sm->prof[13] += sm->pstamp[13] - sm->pstamp[12]; // column metadata + column hash
+                sm->prof[14] += sm->pstamp[14] - sm->pstamp[13]; // row hash + room sums
+                sm->prof[15] += sm->pstamp[1] - sm->pstamp[14]; // barrier after the search
+            }
         }
 #endif
 
@@ -1309,7 +1326,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         S->d3_hits += sm->d3;
         for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
 #ifdef BLU_PROFILE
-        for (int k = 0; k < 8; k++) S->prof[k] += sm->prof[k];
+        for (int k = 0; k < 16; k++) S->prof[k] += sm->prof[k];
 #endif
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }

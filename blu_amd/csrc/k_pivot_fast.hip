@@ -23,12 +23,10 @@ __device__ __forceinline__ unsigned hslot(int k, int bits) { return ((unsigned)k
 __device__ __forceinline__ void hrow_insert(Fast *f, int k, int v)
 {
     unsigned s = hslot(k, 8);
+    const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)v;
     for (;;) {
-        const int old = atomicCAS(&f->hRowK[s], -1, k);
-        if (old == -1 || old == k) {
-            f->hRowV[s] = v;
-            return;
-        }
+        const unsigned long long old = atomicCAS(&f->hRow[s], ~0ull, want);
+        if (old == ~0ull || (int)(old >> 32) == k) return;
         s = (s + 1) & (HROW - 1);
     }
 }
@@ -36,9 +34,9 @@ __device__ __forceinline__ int hrow_lookup(const Fast *f, int k)
 {
     unsigned s = hslot(k, 8);
     for (;;) {
-        const int kk = f->hRowK[s];
-        if (kk == k) return f->hRowV[s];
-        if (kk == -1) return 0;
+        const unsigned long long x = f->hRow[s];
+        if ((int)(x >> 32) == k) return (int)(x & 0xffffffffull);
+        if (x == ~0ull) return 0;
         s = (s + 1) & (HROW - 1);
     }
 }
@@ -72,12 +70,103 @@ struct InHRow {
 
 // Batched list_move (see wave_list_move_batch in k_pivot.hip) with the set of moved elements given
 // as a membership predicate instead of a mark array.  elems/keys may live in LDS.
+// `gone` (>= 0): one more element of the set that is only unlinked, not re-appended (the pivot
+// column / pivot row, list.rs:81-86 at the end of every pivot path).
 template <class InSet>
-__device__ int wave_list_move_batch_set(int *flink, int *blink, int nelem, const int *elems, const int *keys, int n,
-                                        InSet inS, int big)
+__device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
+                                        InSet inS, int big, int gone, int *scratch /* 320 ints of LDS */)
 {
     const int lane = lane_id();
     int minkey = big;
+    if (n < 64) {
+        // Single pass, one memory round trip.  Lane n unlinks `gone`.
+        // Single pass: the three loads per element (its two links and the tail of its new list) are
+        // independent, so the whole batch costs one memory round trip plus the stores.  The tail read
+        // here is the tail BEFORE the unlinks; if that element is itself being moved, the real tail is
+        // its nearest unmoved predecessor (links of moved elements are not modified by the unlinks).
+        // Unlink stores are issued before append stores; stores of one wave to one address keep order.
+        const int key = lane < n ? keys[lane] : -1;
+        bool act = key >= 0;
+        const bool unl = act || (lane == n && gone >= 0); // elements to unlink
+        const int e = act ? elems[lane] : (unl ? gone : 0);
+        int p = 0, nx = 0, t = 0;
+        if (unl) {
+            p = blink[e];
+            nx = flink[e];
+        }
+        if (act) {
+            t = blink[nelem + key];
+            if (key > 0) minkey = key;
+        }
+        // Runs of adjacent moved elements are common (lines updated together were appended together),
+        // so "next unmoved element" / "previous unmoved element" are found by pointer jumping over the
+        // wave's own (element, pred, succ) triples in LDS, never by chasing links through memory.
+        int *bE = scratch, *bP = scratch + 64, *bN = scratch + 128, *bS = scratch + 192, *bQ = scratch + 256;
+#ifdef BLU_PROFILE
+        if (lane == 0) ((long long *)(scratch + 300))[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        bE[lane] = unl ? e : -1;
+        bP[lane] = p;
+        bN[lane] = nx;
+        wave_mem_sync();
+#ifdef BLU_PROFILE
+        if (lane == 0) ((long long *)(scratch + 300))[1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        int sl = -1, pl = -1, tl = -1; // lanes holding my successor / my predecessor / the old tail of my new list
+        const int emine = unl ? e : -1;
+        for (int l2 = 0; l2 <= n; l2++) {
+            const int el = __builtin_amdgcn_readlane(emine, l2); // broadcast from a register: no LDS latency per step
+            if (el >= 0) {
+                if (el == nx) sl = l2;
+                if (el == p) pl = l2;
+                if (act && el == t) tl = l2;
+            }
+        }
+        bS[lane] = sl;
+        bQ[lane] = pl;
+        wave_mem_sync();
+        if (unl && pl < 0) { // first of a run: link its unmoved predecessor to the first unmoved successor
+            int cur = sl;
+            for (int guard = 0; cur >= 0 && guard <= n + 1; guard++) {
+                nx = bN[cur];
+                cur = bS[cur];
+            }
+            flink[p] = nx;
+            blink[nx] = p;
+        }
+        if (act) { // the old tail is being moved itself: the real tail is its nearest unmoved predecessor
+            int cur = tl;
+            for (int guard = 0; cur >= 0 && guard <= n + 1; guard++) {
+                t = bP[cur];
+                cur = bQ[cur];
+            }
+        }
+        if (lane == n && gone >= 0) { // list.rs:84-85: a removed element links to itself
+            flink[gone] = gone;
+            blink[gone] = gone;
+        }
+        // neighbours inside the new list: nearest lanes below / above with the same key.  Every lane
+        // scans the (LDS-resident) key array; the reads are broadcasts, there is no per-key serial loop.
+        int prevl = -1, nextl = -1;
+        for (int l2 = 0; l2 < n; l2++) {
+            const int k2 = __builtin_amdgcn_readlane(key, l2);
+            if (k2 == key) {
+                if (l2 < lane) prevl = l2;
+                else if (l2 > lane && nextl < 0) nextl = l2;
+            }
+        }
+        if (act) {
+            blink[e] = prevl >= 0 ? elems[prevl] : t;
+            flink[e] = nextl >= 0 ? elems[nextl] : nelem + key;
+            if (prevl < 0) flink[t] = e;
+            if (nextl < 0) blink[nelem + key] = e;
+        }
+        return wave_min_i(minkey); // no drain here: the workgroup barrier that follows waits for the stores
+    }
+    if (gone >= 0) { // long batches: unlink `gone` first, as the general path does
+        if (lane == 0) list_remove1(flink, blink, gone);
+        wave_mem_sync();
+    }
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int q = c0 + lane;
         if (q < n && keys[q] >= 0) {
@@ -130,16 +219,17 @@ __device__ int wave_list_move_batch_set(int *flink, int *blink, int nelem, const
 // On return true: sm->pr/pc set (pr = -1: empty column; pc = -1: error), and for a real pivot
 // sm->pcb/prb/nzc/nzr, the L/U room check (sm->exit_code) and fa->kind.
 // ------------------------------------------------------------------------------------------------
-__device__ bool markowitz_fast(const DevLU &D, Sm *sm)
+__device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
 {
     const int lane = lane_id();
     const int m = D.m;
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
-    if (K < 1 || K > KCMAX) return false;
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost*256 + position must fit 64 bits)
     if (lane == 0) fa->kind = 0;
 
+    PROF_STAMP(8);
     const int h0 = D.cflink[m];
     if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
         if (lane == 0) {
@@ -185,6 +275,7 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
         }
         nz += 64;
     }
+    PROF_STAMP(9); // candidates walked (list heads + up to K link/meta loads)
     if (bad || ncand == 0) { // reference: assert / D2 / "no pivot found" assert
         DEV_CHECK(S, false);
         if (lane == 0) {
@@ -229,8 +320,12 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
             }
         }
     }
-    const long long mn = wave_min_ll(mcb);
-    if (mn == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
+    PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
+    // lexicographic min over (cost, flat position) in ONE LDS atomic: key = cost * 256 + position
+    // (position < STGMAX <= 256, cost < 2^55); the first-seen entry wins ties (markowitz.rs:105)
+    const long long bestkey = wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
+    wave_mem_sync();
+    if (bestkey == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
         DEV_CHECK(S, false);
         if (lane == 0) {
             sm->pc = -1;
@@ -238,8 +333,7 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
         }
         return true;
     }
-    const int fsel = wave_min_i(mcb == mn ? fb : 0x7fffffff); // first-seen entry wins ties
-    wave_mem_sync();
+    const int fsel = (int)(bestkey & 255LL);
     const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
     const int pc = fa->cJ[csel], pr = fa->sI[fsel];
     const int nzc = fa->cL[csel], pcb = fa->cB[csel], where = fsel - fa->cOff[csel];
@@ -266,6 +360,7 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
         }
     }
     DEV_CHECK(S, nzr >= 1 && nzc >= 1);
+    PROF_STAMP(11); // pivot chosen
     int kind = 0;
     if (nzr >= 2 && nzr <= PRMAX) {
         if (nzc == 1) kind = 2;
@@ -298,7 +393,8 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
         if (lane == 0) sm->pc = -1;
         return true;
     }
-    for (int s = lane; s < HROW; s += 64) fa->hRowK[s] = -1;
+    PROF_STAMP(12); // pivot column copied, pivot row loaded
+    for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
     for (int s = lane; s < HCOL; s += 64) fa->hColK[s] = -1;
     long long gc = 0, gr = 0;
 #pragma unroll
@@ -319,6 +415,7 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
             }
         }
     }
+    PROF_STAMP(13); // line metadata of the pivot row's columns loaded, column hash built
     if (kind == 1) {
         for (int p = 1 + lane; p < nzc; p += 64) {
             hrow_insert(fa, fa->pcI[p], p);
@@ -334,13 +431,16 @@ __device__ bool markowitz_fast(const DevLU &D, Sm *sm)
         fa->kind = kind;
         fa->where = wpos;
     }
+    PROF_STAMP(14);
     return true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // kind 1: pivot_small (pivot.rs:460-833), column q of the pivot row, ONE wave
 // ------------------------------------------------------------------------------------------------
-__device__ void fast_col(const DevLU &D, Sm *sm, int q, double *work)
+// idx_first/val_first: this lane's entry of the first 64-entry chunk, loaded by the caller ahead of
+// time (the caller issues the loads of all its tasks before processing any of them)
+__device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *work, int idx_first, double val_first)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -358,8 +458,8 @@ __device__ void fast_col(const DevLU &D, Sm *sm, int q, double *work)
     for (int c = 0; c < cl; c += 64) {
         const int e = c + lane;
         const bool v = e < cl;
-        const int idx = v ? D.cidx[cb + e] : 0;
-        const double val = v ? D.cval[cb + e] : 0.0;
+        const int idx = c == 0 ? idx_first : (v ? D.cidx[cb + e] : 0);
+        const double val = c == 0 ? val_first : (v ? D.cval[cb + e] : 0.0);
         const int mk = v ? hrow_lookup(fa, idx) : 0;
         const bool keep = v && mk == 0;
         if (v && mk > 0) work[mk - 1] = val;
@@ -448,6 +548,8 @@ __device__ void fast_col(const DevLU &D, Sm *sm, int q, double *work)
     }
     const unsigned long long mask = __ballot(p && !kx);
     const int nadd = __popcll(kb);
+    // column maximum: LDS atomic max on the bit patterns (non-negative doubles order like integers);
+    // one LDS round trip instead of a 6-step cross-lane reduction
     const double cmx = wave_max_d(cmxl);
     if (lane == 0) {
         const int newlen = nk1 + nadd;
@@ -467,7 +569,7 @@ __device__ void fast_col(const DevLU &D, Sm *sm, int q, double *work)
 
 // kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
 // cancelled by fast_col are removed afterwards by fast_fixrow.
-__device__ void fast_row(const DevLU &D, Sm *sm, int p)
+__device__ __forceinline__ void fast_row(const DevG &D, Sm *sm, int p, int j_first)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -482,7 +584,7 @@ __device__ void fast_row(const DevLU &D, Sm *sm, int p)
     for (int c = 0; c < rl; c += 64) {
         const int e = c + lane;
         const bool v = e < rl;
-        const int j = v ? D.ridx[rb + e] : -1;
+        const int j = c == 0 ? j_first : (v ? D.ridx[rb + e] : -1);
         const bool keep = v && !hcol_has(fa, j);
         if (__ballot(v && j == pc)) found = true;
         const unsigned long long kb = __ballot(keep);
@@ -530,7 +632,7 @@ __device__ void fast_row(const DevLU &D, Sm *sm, int p)
 }
 
 // rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
-__device__ void fast_fixrow(const DevLU &D, Sm *sm, int p)
+__device__ __forceinline__ void fast_fixrow(const DevG &D, Sm *sm, int p)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -551,7 +653,7 @@ __device__ void fast_fixrow(const DevLU &D, Sm *sm, int p)
 }
 
 // U row from the LDS copies (pivot.rs:306-312): slots q0..q1 of the pivot row except skipq
-__device__ void fast_write_u(const DevLU &D, Sm *sm, int q0, int q1, int skipq)
+__device__ __forceinline__ void fast_write_u(const DevG &D, Sm *sm, int q0, int q1, int skipq)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -576,7 +678,7 @@ __device__ void fast_write_u(const DevLU &D, Sm *sm, int q0, int q1, int skipq)
 }
 
 // L column from the LDS copy (pivot.rs:404-416): slots 1..cnz1
-__device__ void fast_write_l(const DevLU &D, Sm *sm)
+__device__ __forceinline__ void fast_write_l(const DevG &D, Sm *sm)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -605,7 +707,7 @@ __device__ void fast_write_l(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ void fast_small(const DevLU &D, Sm *sm)
+__device__ __forceinline__ void fast_small(const DevG &D, Sm *sm)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -615,11 +717,38 @@ __device__ void fast_small(const DevLU &D, Sm *sm)
     DEV_CHECK(D.s, fa->pcV[0] != 0.0);
 
     double *work = &sm->swork[w * 64];
+    // tasks 0..rnz1-1 = columns of the pivot row, rnz1.. = rows of the pivot column; wave w takes
+    // t = w, w+nw, ...  Three tasks at a time: all first-chunk loads are issued before any of the
+    // lines is processed, so their latencies overlap instead of adding up.
     const int ntask = rnz1 + cnz1;
-    for (int t = w; t < ntask; t += nw) {
-        if (t < rnz1) fast_col(D, sm, t + 1, work);
-        else fast_row(D, sm, t - rnz1 + 1);
+    PROF_STAMP(4);
+    for (int t0 = w; t0 < ntask; t0 += 3 * nw) {
+        int li[3];
+        double lv[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int t = t0 + u * nw;
+            li[u] = -1;
+            lv[u] = 0.0;
+            if (t < rnz1) {
+                const int q = t + 1;
+                if (lane < fa->tL[q]) {
+                    li[u] = D.cidx[fa->tB[q] + lane];
+                    lv[u] = D.cval[fa->tB[q] + lane];
+                }
+            } else if (t < ntask) {
+                const int p = t - rnz1 + 1;
+                if (lane < fa->prL[p]) li[u] = D.ridx[fa->prB[p] + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int t = t0 + u * nw;
+            if (t < rnz1) fast_col(D, sm, t + 1, work, li[u], lv[u]);
+            else if (t < ntask) fast_row(D, sm, t - rnz1 + 1, li[u]);
+        }
     }
+    PROF_STAMP(5);
     __syncthreads();
     PROF_STAMP(3);
     if (fa->anycancel) {
@@ -634,18 +763,23 @@ __device__ void fast_small(const DevLU &D, Sm *sm)
             D.rlen[pr] = 0;
             sm->kinds[3]++;
         }
+        PROF_STAMP(6);
     }
     if (w == 1 % nw) fast_write_l(D, sm);
     if (w == 2 % nw) {
-        if (lane == 0) list_remove1(D.cflink, D.cblink, pc);
-        wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa}, m + 2);
+#ifdef BLU_PROFILE
+        if (lane == 0) sm->pstamp[7] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa}, m + 2, pc, fa->ls[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
+#ifdef BLU_PROFILE
+        if (lane == 0) sm->pstamp[8] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     }
     if (D.search_rows && w == 3 % nw) {
-        if (lane == 0) list_remove1(D.rflink, D.rblink, pr);
+        if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2);
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1]);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
     __syncthreads();
@@ -654,7 +788,7 @@ __device__ void fast_small(const DevLU &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ void fast_scol(const DevLU &D, Sm *sm)
+__device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -711,12 +845,9 @@ __device__ void fast_scol(const DevLU &D, Sm *sm)
         }
     }
     if (w == 1 % nw) {
-        if (lane == 0) {
-            list_remove1(D.cflink, D.cblink, pc);
-            if (D.search_rows) list_remove1(D.rflink, D.rblink, pr);
-        }
-        wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa}, m + 2);
+        if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
+        // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa}, m + 2, pc, fa->ls[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
     }
     __syncthreads();

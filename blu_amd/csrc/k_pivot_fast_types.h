@@ -24,6 +24,8 @@ struct Fast {
     // staged candidate entries
     int sI[STGMAX], sB[STGMAX], sL[STGMAX], sC[STGMAX];
     double sV[STGMAX];
-    int hRowK[HROW], hRowV[HROW], hColK[HCOL];
+    unsigned long long hRow[HROW]; // (row index << 32) | position, ~0 = empty: one LDS read per probe
+    int hColK[HCOL];
+    int ls[2][320]; // scratch of the batched list moves (0: column lists, 1: row lists)
 };
 

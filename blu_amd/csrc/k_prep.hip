@@ -14,7 +14,7 @@
 // keys[e] < 0 : element is not inserted.  Equivalent to `for e in 0..n { list_add(e, keys[e]) }`
 // (list.rs:54-77).  Returns the minimum key > 0 seen (or big).
 // ---------------------------------------------------------------------------------------------
-__device__ int wave_list_build(int *flink, int *blink, int n, const int *keys, int big)
+__device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, int big)
 {
     const int lane = lane_id();
     int minkey = big;
@@ -52,7 +52,7 @@ __device__ int wave_list_build(int *flink, int *blink, int n, const int *keys, i
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ int sh[40];
     __shared__ long long shl[20];
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             if (i >= (unsigned long long)m) {
                 bad = 1;
             } else {
-                atomicAdd(&D.iw0[(int)i], 1);
+                g_atomic_add(&D.iw0[(int)i], 1);
                 D.bc_idx[put] = (int)i;
                 D.bc_val[put] = D.b_x[pos];
             }
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
     for (int j = tid; j < m; j += nt) {
         for (int pos = D.bc_ptr[j]; pos < D.bc_ptr[j + 1]; pos++) {
             const int i = D.bc_idx[pos];
-            const int p = atomicAdd(&D.iw1[i], 1);
+            const int p = g_atomic_add(&D.iw1[i], 1);
             D.bt_idx[p] = j;
             D.bt_val[p] = D.bc_val[pos];
         }
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         for (int j = tid; j < m; j += nt) D.iw0[j] = 0;
         __syncthreads();
         for (int p = b + tid; p < e; p += nt)
-            if (atomicAdd(&D.iw0[D.bt_idx[p]], 1) != 0) bad = 1; // duplicate
+            if (g_atomic_add(&D.iw0[D.bt_idx[p]], 1) != 0) bad = 1; // duplicate
         __syncthreads();
         int rb = 0;
         for (int c0 = 0; c0 < m; c0 += nt) {
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
                     const int i = D.bc_idx[D.bc_ptr[j]];
                     const double piv = D.bc_val[D.bc_ptr[j]];
                     DEV_CHECK(S, D.pinv[i] < 0);
-                    if (!(piv == 0.0 || fabs(piv) < abstol)) atomicMin(&D.iw0[i], j);
+                    if (!(piv == 0.0 || fabs(piv) < abstol)) g_atomic_min(&D.iw0[i], j);
                 }
             } else {
                 const int i = e;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
                     const int j = D.bt_idx[D.bt_ptr[i]];
                     const double piv = D.bt_val[D.bt_ptr[i]];
                     DEV_CHECK(S, D.qinv[j] < 0);
-                    if (!(piv == 0.0 || fabs(piv) < abstol)) atomicMin(&D.iw0[j], i);
+                    if (!(piv == 0.0 || fabs(piv) < abstol)) g_atomic_min(&D.iw0[j], i);
                 }
             }
         }
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ int sh[40];
     __shared__ long long shl[20];

@@ -12,13 +12,13 @@
 
 __global__ void __launch_bounds__(1024) k_solve_dense(DevLU *Ds, FinishOut *Os, const double *rhs_all, double *lhs_all, int trans)
 {
-    const DevLU &D = Ds[blockIdx.x];
+    const DevG D(Ds[blockIdx.x]);
     const FinishOut &O = Os[blockIdx.x];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
     const int m = D.m;
     const double *rhs = rhs_all + (size_t)blockIdx.x * m;
     double *lhs = lhs_all + (size_t)blockIdx.x * m;
-    double *y = D.txrj; // m+2 doubles of scratch, permuted coordinates
+    gdouble_p y = D.txrj; // m+2 doubles of scratch, permuted coordinates
 
     // gather the right-hand side into pivot order
     for (int k = tid; k < m; k += nt) y[k] = rhs[trans ? O.colperm[k] : O.rowperm[k]];

@@ -12,7 +12,7 @@ if len(sys.argv) > 2:
     h.dbg_set_block(int(sys.argv[2]))
 for rep in range(2):
     st = h.factorize(cp[:-1], cp[1:], ri, v)
-p = [h.stat(60 + k) for k in range(8)]
+p = [h.stat(60 + k) for k in range(16)]
 tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
 tot = sum(p[:4])
 print("status", st, "t_pivot %.1f ms" % (1e3 * tp), "ticks total %.3g -> %.2f GHz-equivalent" % (tot, tot / tp / 1e9))
@@ -22,3 +22,5 @@ print("search+setup: %.2f us/pivot (%.0f%%)" % (p[0] * f / max(1, n1 + n2 + n3),
 print("fast small  : n=%d %.2f us each (%.0f%%), of which line updates %.2f us" % (n1, p[1] * f / max(1, n1), 100 * p[1] / tot, p[7] * f / max(1, n1)))
 print("fast scol   : n=%d %.2f us each (%.0f%%)" % (n2, p[2] * f / max(1, n2), 100 * p[2] / tot))
 print("general     : n=%d %.2f us each (%.0f%%)" % (n3, p[3] * f / max(1, n3), 100 * p[3] / tot))
+names = ["enter", "walk lists", "entries+rowmeta+cost", "argmin", "pivot col->LDS, row load", "col metadata+hash", "row hash+sums", "barrier"]
+print("search stages (us per fast pivot): " + " | ".join("%s %.2f" % (nm, p[8 + k] * f / max(1, n1 + n2)) for k, nm in enumerate(names)))
