@@ -165,6 +165,12 @@ def main():
     bytes_elim = 32.0 * F + 32.0 * (l_nz + u_nz)
     bytes_all = 16.0 * (nnz + m) + bytes_elim
     t_kernel = t_pivot / max(1, nlaunch)  # average k_pivot_loop launch
+    # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this command,
+    # recorded under profiles/ (PMC can not be collected from inside this script)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pivot_loop_traffic.json")
+    if args.config == "C3" and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"] / max(t_kernel, 1e-12) / 1e9
     achieved = bytes_elim * args.steps / max(t_pivot, 1e-12) / 1e9
     out = {
         "metric": "factorize nnz/s + achieved HBM GB/s, 100k x 100k 10-nnz/col basis",
@@ -185,7 +191,8 @@ def main():
                    "rank": h.stat(K.STAT_RANK), "bump_size": h.stat(K.STAT_BUMP_SIZE),
                    "nsearch_pivot": h.stat(K.STAT_NSEARCH_PIVOT), "parallelism": "one basis per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "k_pivot_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pivot_loop_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch / avg launch time, GB/s)",
                      "algorithmic_bytes_per_launch": bytes_elim * args.steps / max(1, nlaunch),
                      "avg_launch_ms": 1e3 * t_kernel, "launches_per_step": nlaunch / args.steps},
         "achieved_GBs_whole_factorize": bytes_all * args.steps / elapsed / 1e9,
