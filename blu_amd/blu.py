@@ -233,6 +233,11 @@ class BLU:
         if st != K.OK:
             raise BluError(st)
 
+    def set_skip_stats(self, on=True):
+        """Skip the statistics tail of factorize() (condest, residual_test); default: computed, as the reference."""
+        lib().blu_hip_set_skip_stats.argtypes = [C.c_void_p, C.c_int]
+        lib().blu_hip_set_skip_stats(self._h, int(bool(on)))
+
     def dbg_set_no_fast(self, on=True):
         """Run the general pivot paths only (k_pivot_fast.hip off): A/B of the two implementations."""
         lib().blu_hip_dbg_set_no_fast.argtypes = [C.c_void_p, C.c_int]

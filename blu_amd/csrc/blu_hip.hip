@@ -20,6 +20,7 @@
 #include "k_pivot.hip"
 #include "k_prep.hip"
 #include "k_solve.hip"
+#include "k_stats.hip"
 
 #define BLU_STOPPED_STATUS 100 /* debug stepping only */
 
@@ -56,6 +57,7 @@ struct blu_hip {
     int relaunches;
     int block_threads; // workgroup size of the pivot kernel
     int no_fast;       // debug: disable the LDS fast paths
+    int skip_stats;    // 1: do not compute condest / residual_test inside factorize (keys return 0)
     std::string err;
     int64_t stop_at;   // debug: -1 off
 };
@@ -480,6 +482,13 @@ extern "C" int blu_hip_dbg_set_stop(blu_hip *h, int64_t stop_at)
 {
     if (!h) return BLU_ERROR_ARGUMENT_MISSING;
     h->stop_at = stop_at;
+    return BLU_OK;
+}
+// 1 = skip the statistics tail of factorize() (condest, residual_test); default 0 = compute, as the reference
+extern "C" int blu_hip_set_skip_stats(blu_hip *h, int on)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    h->skip_stats = on ? 1 : 0;
     return BLU_OK;
 }
 extern "C" int blu_hip_dbg_set_batch_block(blu_hip *h, int threads)

@@ -1,0 +1,295 @@
+// k_stats.hip -- the statistics tail of factorize() (src/factorize.rs:121-147), one workgroup per matrix:
+//   condest(L), condest(U)   src/lu/condest.rs:15-157   (LINPACK 1-norm condition estimates)
+//   residual_test            src/lu/residual_test.rs:16-152 (+ matrix_norm, src/lu/matrix_norm.rs:8-48)
+//
+// The four triangular-sweep chains (condest L, condest U, residual forward, residual backward) are
+// independent of each other and run concurrently on four waves; each chain is a dependent sequence of
+// m pivot steps (lanes over the entries of the step's column).  Afterwards the whole workgroup forms the
+// residuals, norms and maxima in parallel.  Everything works in PIVOT-ORDER coordinates on the canonical
+// factors k_finish wrote (O: L unit lower CSC diagonal first, U upper CSC pivot last), i.e. on
+//   B[rowperm, colperm] = L * U,  vector index k <-> row rowperm[k] / column colperm[k].
+//
+// Floating point: dots are accumulated by ONE lane in storage order (the reference's loop order for the
+// U sweeps and the forward L sweep; the L dots of condest/backward use the sorted column instead of the
+// stage order), so values agree with the reference to rounding (tested at 1e-9 relative), and the
+// +-1 right-hand-side choices (`temp >= 0`, `d <= 0`) are made on identically defined quantities.
+#include "blu_dev.h"
+
+// ordered dot: sum_{p in [b,e)} x[idx[p]] * val[p], accumulated sequentially in storage order.
+// Lanes fetch, lane 0 accumulates from LDS (`buf`: 64 doubles of this wave).  All lanes return the sum.
+__device__ __forceinline__ double wave_ordered_dot(const long long *idx, const double *val, long long b, long long e,
+                                                   gdouble_p x, double *buf)
+{
+    const int lane = lane_id();
+    double acc = 0.0;
+    for (long long c = b; c < e; c += 64) {
+        const long long p = c + lane;
+        double prod = 0.0;
+        if (p < e) prod = __dmul_rn(x[(int)idx[p]], val[p]);
+        buf[lane] = prod;
+        wave_mem_sync();
+        if (lane == 0) {
+            const int n = (int)((e - c) < 64 ? (e - c) : 64);
+            for (int t = 0; t < n; t++) acc = __dadd_rn(acc, buf[t]);
+        }
+        wave_mem_sync();
+    }
+    return __shfl(acc, 0);
+}
+
+// same over a stage-ordered L column (row indices of B, optionally mapped to pivot positions by `map`):
+// this IS the reference's storage order for L columns (l_begin_p, pivot.rs:404-416)
+__device__ __forceinline__ double wave_ordered_dot_stage(gcint_p idx, gdouble_p val, int b, int e, gdouble_p x, gcint_p map,
+                                                         double *buf)
+{
+    const int lane = lane_id();
+    double acc = 0.0;
+    for (int c = b; c < e; c += 64) {
+        const int p = c + lane;
+        double prod = 0.0;
+        if (p < e) {
+            const int i = idx[p];
+            prod = __dmul_rn(x[map ? map[i] : i], val[p]);
+        }
+        buf[lane] = prod;
+        wave_mem_sync();
+        if (lane == 0) {
+            const int n = (e - c) < 64 ? (e - c) : 64;
+            for (int t = 0; t < n; t++) acc = __dadd_rn(acc, buf[t]);
+        }
+        wave_mem_sync();
+    }
+    return __shfl(acc, 0);
+}
+
+__global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
+{
+    const DevG D(Ds[blockIdx.x]);
+    const FinishOut &O = Os[blockIdx.x];
+    Scalars *S = D.s;
+    __shared__ double bufs[4][64];
+    __shared__ double red[4][40];
+    __shared__ double chain_out[16];
+    const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), lane = lane_id(), nw = num_waves();
+    const int m = D.m;
+    if (S->status != ST_DONE) return;
+    const int rank = S->rank;
+    // six m-vectors in the (all-zero) pivot_any work area; re-zeroed at the end
+    gdouble_p wl = D.gwork, wu = D.gwork + (size_t)(m + 1), lf = D.gwork + 2 * (size_t)(m + 1),
+              rf = D.gwork + 3 * (size_t)(m + 1), lb = D.gwork + 4 * (size_t)(m + 1), rb = D.gwork + 5 * (size_t)(m + 1);
+    gdouble_p rs = D.gwork + 6 * (size_t)(m + 1); // row sums of |B|
+
+    const int chain = nw >= 4 ? w : -1;
+    for (int cc = 0; cc < 4; cc++) {
+        // with fewer than 4 waves the chains run one after the other on wave 0
+        const bool mine = nw >= 4 ? (w == cc) : (w == 0);
+        if (!mine) continue;
+        double *buf = bufs[nw >= 4 ? cc : 0];
+        if (cc == 0) {
+            // ---- condest(L): L' x = b with b = +-1 chosen on the fly, k descending (condest.rs:101-116, upper = 0)
+            // This chain works in ROW-INDEX coordinates on the stage-ordered L columns, the reference's own
+            // storage and summation order (wl[i], i = row of B).
+            double x1 = 0.0, xinf = 0.0;
+            for (int k = m - 1; k >= 0; k--) {
+                const int b = D.lbeg[k], e = D.lbeg[k + 1];
+                double temp = 0.0;
+                if (e > b) temp = -wave_ordered_dot_stage(D.lidx, D.lval, b, e, wl, nullptr, buf); // temp -= work[i]*x
+                temp += temp >= 0.0 ? 1.0 : -1.0;
+                if (lane == 0) wl[D.prow[k]] = temp;
+                x1 += fabs(temp);
+                xinf = fmax(xinf, fabs(temp));
+                wave_mem_sync();
+            }
+            // L y = x, k ascending, scatter (condest.rs:135-154)
+            double y1 = 0.0;
+            for (int k = 0; k < m; k++) {
+                const int b = D.lbeg[k], e = D.lbeg[k + 1];
+                const double temp = wl[D.prow[k]];
+                for (int p = b + lane; p < e; p += 64) {
+                    const int r = D.lidx[p];
+                    wl[r] = __dsub_rn(wl[r], __dmul_rn(temp, D.lval[p]));
+                }
+                y1 += fabs(temp);
+                if (e > b) wave_mem_sync();
+            }
+            if (lane == 0) {
+                chain_out[0] = fmax(y1 / x1, xinf); // normest_l_inv
+            }
+        } else if (cc == 1) {
+            // ---- condest(U): U' x = b, k ascending, then U y = x, k descending (upper = 1, pivots = diagonal)
+            double x1 = 0.0, xinf = 0.0;
+            for (int k = 0; k < m; k++) {
+                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+                double temp = 0.0;
+                if (e > b) temp = -wave_ordered_dot(O.u_rowidx, O.u_value, b, e, wu, buf);
+                temp += temp >= 0.0 ? 1.0 : -1.0;
+                temp /= O.u_value[e];
+                if (lane == 0) wu[k] = temp;
+                x1 += fabs(temp);
+                xinf = fmax(xinf, fabs(temp));
+                wave_mem_sync();
+            }
+            double y1 = 0.0;
+            for (int k = m - 1; k >= 0; k--) {
+                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+                const double temp = wu[k] / O.u_value[e];
+                if (lane == 0) wu[k] = temp;
+                for (long long p = b + lane; p < e; p += 64) {
+                    const int r = (int)O.u_rowidx[p];
+                    wu[r] = __dsub_rn(wu[r], __dmul_rn(temp, O.u_value[p]));
+                }
+                y1 += fabs(temp);
+                wave_mem_sync();
+            }
+            if (lane == 0) chain_out[1] = fmax(y1 / x1, xinf); // normest_u_inv
+        } else if (cc == 2) {
+            // ---- residual test, forward system (residual_test.rs:43-66): lhs = L\rhs with rhs = +-1 on the fly.
+            // The reference takes row dots of L; the column scatter below adds the same products to each
+            // accumulator in the same (ascending stage) order.  lf[k] first accumulates d, then holds lhs.
+            for (int k = 0; k < m; k++) {
+                const double d = lf[k];
+                const double r = d <= 0.0 ? 1.0 : -1.0;
+                const double x = r - d;
+                if (lane == 0) {
+                    rf[k] = r;
+                    lf[k] = x;
+                }
+                const long long b = O.l_colptr[k] + 1, e = O.l_colptr[k + 1];
+                for (long long p = b + lane; p < e; p += 64) {
+                    const int rr = (int)O.l_rowidx[p];
+                    lf[rr] = __dadd_rn(lf[rr], __dmul_rn(x, O.l_value[p]));
+                }
+                wave_mem_sync();
+            }
+            // overwrite lhs by U\lhs, k descending (residual_test.rs:57-66)
+            for (int k = m - 1; k >= 0; k--) {
+                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+                const double d = lf[k] / O.u_value[e];
+                if (lane == 0) lf[k] = d;
+                for (long long p = b + lane; p < e; p += 64) {
+                    const int r = (int)O.u_rowidx[p];
+                    lf[r] = __dsub_rn(lf[r], __dmul_rn(d, O.u_value[p]));
+                }
+                wave_mem_sync();
+            }
+        } else {
+            // ---- residual test, backward system (residual_test.rs:85-108): lhs = U'\rhs, then L'\lhs
+            for (int k = 0; k < m; k++) {
+                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+                double d = 0.0;
+                if (e > b) d = wave_ordered_dot(O.u_rowidx, O.u_value, b, e, lb, buf);
+                const double r = d <= 0.0 ? 1.0 : -1.0;
+                if (lane == 0) {
+                    rb[k] = r;
+                    lb[k] = (r - d) / O.u_value[e];
+                }
+                wave_mem_sync();
+            }
+            for (int k = m - 1; k >= 0; k--) { // dots with the stage-ordered L columns (rows mapped to positions)
+                const int b = D.lbeg[k], e = D.lbeg[k + 1];
+                if (e > b) {
+                    const double d = wave_ordered_dot_stage(D.lidx, D.lval, b, e, lb, D.pinv, buf);
+                    if (lane == 0) lb[k] = lb[k] - d;
+                    wave_mem_sync();
+                }
+            }
+        }
+    }
+    (void)chain;
+    __syncthreads();
+
+    // ---- norms of L and U (condest.rs:27-44), 1-norm = max column sum
+    double nl = 0.0, nu = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        double s = 1.0;
+        for (long long p = O.l_colptr[k] + 1; p < O.l_colptr[k + 1]; p++) s += fabs(O.l_value[p]);
+        nl = fmax(nl, s);
+        const long long e = O.u_colptr[k + 1] - 1;
+        double t = fabs(O.u_value[e]);
+        for (long long p = O.u_colptr[k]; p < e; p++) t += fabs(O.u_value[p]);
+        nu = fmax(nu, t);
+    }
+    // ---- residuals (residual_test.rs:68-83, 110-126) and matrix norms (matrix_norm.rs), pivot coordinates:
+    // column k of the factorized matrix is column colperm[k] of B for k < rank, the unit vector e_k otherwise
+    for (int i = tid; i < m; i += nt) rs[i] = 0.0;
+    __syncthreads();
+    double one = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        if (k < rank) {
+            const int j = D.pcol[k];
+            double cs = 0.0, d = 0.0;
+            for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
+                const double a = D.bc_val[p];
+                cs += fabs(a);
+                d = __dadd_rn(d, __dmul_rn(lb[D.pinv[D.bc_idx[p]]], a)); // B' * lhs, column order of B
+            }
+            one = fmax(one, cs);
+            rb[k] = rb[k] - d;
+        } else {
+            one = fmax(one, 1.0);
+            rb[k] = rb[k] - lb[k];
+        }
+    }
+    // forward residual rhs - B*lhs and row sums: one thread per ROW of B (bt_* = B row-wise, sorted by column)
+    for (int i = tid; i < m; i += nt) {
+        const int kr = D.pinv[i];
+        double acc = rf[kr], rsum = 0.0;
+        for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) {
+            const int kc = D.qinv[D.bt_idx[p]];
+            if (kc < rank) {
+                const double a = D.bt_val[p];
+                acc = __dsub_rn(acc, __dmul_rn(lf[kc], a));
+                rsum += fabs(a);
+            }
+        }
+        if (kr >= rank) {
+            acc = acc - lf[kr];
+            rsum += 1.0;
+        }
+        rf[kr] = acc;
+        rs[i] = rsum;
+    }
+    __syncthreads();
+    double s_lf = 0.0, s_rf = 0.0, s_lb = 0.0, s_rb = 0.0, inf = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        s_lf += fabs(lf[k]);
+        s_rf += fabs(rf[k]);
+        s_lb += fabs(lb[k]);
+        s_rb += fabs(rb[k]);
+        inf = fmax(inf, rs[k]);
+    }
+    // workgroup reductions: sums and maxima
+    double vals[8] = {s_lf, s_rf, s_lb, s_rb, nl, nu, one, inf};
+    for (int q = 0; q < 8; q++) {
+        double v = vals[q];
+        if (q < 4) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        } else {
+            v = wave_max_d(v);
+        }
+        if (lane == 0) red[q & 3][w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double a = red[q & 3][0];
+            for (int ww = 1; ww < nw; ww++) a = q < 4 ? a + red[q & 3][ww] : fmax(a, red[q & 3][ww]);
+            chain_out[4 + q] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double nf = chain_out[4], nrf = chain_out[5], nb = chain_out[6], nrb = chain_out[7];
+        S->norm_l = chain_out[8];
+        S->norm_u = chain_out[9];
+        S->onenorm = chain_out[10];
+        S->infnorm = chain_out[11];
+        S->normest_l_inv = chain_out[0];
+        S->normest_u_inv = chain_out[1];
+        S->condest_l = chain_out[8] * chain_out[0];
+        S->condest_u = chain_out[9] * chain_out[1];
+        S->residual_test = fmax(nrf / ((double)m + chain_out[10] * nf), nrb / ((double)m + chain_out[11] * nb));
+    }
+    // restore the all-zero invariant of the pivot_any work area
+    const size_t ng = (size_t)7 * (m + 1);
+    for (size_t e = tid; e < ng; e += nt) D.gwork[e] = 0.0;
+}

@@ -310,3 +310,42 @@ def test_general_paths_only_matches_fast_paths(blu, oracle):
     for k in util.INT_KEYS + util.VAL_KEYS:
         assert np.array_equal(fa[k], fb[k]), k
     assert a.stat(54) > 0 and a.stat(K.STAT_NSEARCH_PIVOT) == b.stat(K.STAT_NSEARCH_PIVOT)
+
+
+FSTATS = ("CONDEST_L", "CONDEST_U", "NORM_L", "NORM_U", "NORMEST_L_INV", "NORMEST_U_INV", "ONENORM", "INFNORM")
+
+
+@pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1000, 10, 12, 1.0, 11, 0.2),
+                                  (1500, 8, 16, 0.2, 3, 1.0)], ids=lambda s: "m%d" % s[0])
+@pytest.mark.parametrize("block", [1024, 128])
+def test_statistics_tail(blu, oracle, spec, block):
+    """condest(L), condest(U), matrix norms, residual_test (factorize.rs:121-147).
+    Norms and condition estimates at 1e-9 relative (same operations, summation order of two L dots differs);
+    residual_test is rounding noise divided by m, compared in magnitude only."""
+    cp, ri, v = oracle.gen_lp_basis(*spec)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, block=block, fix_d3=True)
+    assert sg == so == K.OK
+    for c in FSTATS:
+        a, b = g.stat(getattr(K, "STAT_" + c)), o.stat(getattr(K, "STAT_" + c))
+        assert abs(a - b) <= 1e-9 * abs(b), (c, a, b)
+    a, b = g.stat(K.STAT_RESIDUAL_TEST), o.stat(K.STAT_RESIDUAL_TEST)
+    assert 0.0 < a < 1e-10 and a < 50 * b + 1e-18 and b < 50 * a + 1e-18, (a, b)
+    a, b = g.stat(K.STAT_UPDATE_COST_DENOM), o.stat(K.STAT_UPDATE_COST_DENOM)
+    assert abs(a - b) <= 1e-12 * abs(b)
+
+
+def test_statistics_tail_singular_and_skip(blu, oracle):
+    cp, ri, v = oracle.gen_lp_basis(900, 7, 8, 0.5, 21, 0.4)
+    v = v.copy()
+    for j in (3, 77, 500, 899):
+        v[int(cp[j]):int(cp[j + 1])] *= 1e-17
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
+    assert sg == so == K.WARNING_SINGULAR_MATRIX
+    for c in FSTATS:
+        a, b = g.stat(getattr(K, "STAT_" + c)), o.stat(getattr(K, "STAT_" + c))
+        assert abs(a - b) <= 1e-9 * abs(b), (c, a, b)
+    h = blu.BLU(900, len(ri))
+    h.set_skip_stats(True)
+    assert h.factorize(cp[:-1], cp[1:], ri, v) == K.WARNING_SINGULAR_MATRIX
+    assert h.stat(K.STAT_CONDEST_U) == 0.0
+    util.assert_same_factors(h.get_factors(), o.get_factors())
