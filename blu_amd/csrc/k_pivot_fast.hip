@@ -102,16 +102,10 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
         // so "next unmoved element" / "previous unmoved element" are found by pointer jumping over the
         // wave's own (element, pred, succ) triples in LDS, never by chasing links through memory.
         int *bE = scratch, *bP = scratch + 64, *bN = scratch + 128, *bS = scratch + 192, *bQ = scratch + 256;
-#ifdef BLU_PROFILE
-        if (lane == 0) ((long long *)(scratch + 300))[0] = (long long)__builtin_amdgcn_s_memtime();
-#endif
         bE[lane] = unl ? e : -1;
         bP[lane] = p;
         bN[lane] = nx;
         wave_mem_sync();
-#ifdef BLU_PROFILE
-        if (lane == 0) ((long long *)(scratch + 300))[1] = (long long)__builtin_amdgcn_s_memtime();
-#endif
         int sl = -1, pl = -1, tl = -1; // lanes holding my successor / my predecessor / the old tail of my new list
         const int emine = unl ? e : -1;
         for (int l2 = 0; l2 <= n; l2++) {

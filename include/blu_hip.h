@@ -139,6 +139,17 @@ int blu_hip_factorize_batch(blu_hip **h, int n,
                             const uint64_t *const *b_i, const double *const *b_x,
                             const uint64_t *b_i_len, int inputs_on_device, int *status);
 
+/* factorize() ends with the statistics tail of src/factorize.rs:121-147 (condest(L), condest(U),
+ * residual_test; getters BLU_STAT_CONDEST_* .. BLU_STAT_RESIDUAL_TEST).  It is a chain of 8 triangular
+ * sweeps (~17 % of the factorize time at 100k); a caller that never reads those getters can switch
+ * it off (on != 0): the keys then return 0.  Default: computed, as the reference does. */
+int blu_hip_set_skip_stats(blu_hip *h, int on);
+
+/* Synthetic LP basis used by the benchmark and the tests (host utility, no device
+ * work): CSC out, colptr[m+1], rowidx/value[<= m*k].  Returns nnz. */
+int64_t blu_hip_gen_lp_basis(int64_t m, int64_t k, int64_t bw, double tri_frac, double offscale,
+                             uint64_t seed, uint64_t *colptr, uint64_t *rowidx, double *value);
+
 /* Library/device introspection */
 const char *blu_hip_version(void);
 int blu_hip_device_count(void);
