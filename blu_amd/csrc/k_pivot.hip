@@ -39,15 +39,21 @@ __shared__ int g_pivot_err;
     do {                                                                   \
         if (threadIdx.x == 0) sm->pstamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+// PROF_WAIT: drain this wave's vector-memory operations, so that the stamp that follows separates
+// "loads issued + arrived" from the arithmetic behind them (changes the timing a little: diagnostic only)
+#define PROF_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define PROF_STAMP(k) \
     do {              \
+    } while (0)
+#define PROF_WAIT() \
+    do {            \
     } while (0)
 #endif
 
 struct Sm {
     Fast fa;
-    long long prof[16], pstamp[16];
+    long long prof[24], pstamp[24];
     int pr, pc;
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
@@ -55,10 +61,10 @@ struct Sm {
     int exit_code, need;
     int flag_small;
     int other_row, where, ncancel, nfill;
-    int stop_at, need_search;
+    int stop_at, need_search, head_exit;
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
-    long long kinds[6];
+    long long kinds[12];
     int sh[40];
     long long shl[20];
     double swork[16 * 64];
@@ -1194,43 +1200,48 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->nexpand = 0;
         sm->d3 = 0;
         sm->stop_at = stop_at;
-        for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
-        for (int k = 0; k < 16; k++) sm->prof[k] = 0;
+        sm->fa.qN = 0;
+        sm->fa.kind = 0;
+        for (int k = 0; k < 12; k++) sm->kinds[k] = 0;
+        for (int k = 0; k < 24; k++) sm->prof[k] = 0;
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
     if (tid == 0) g_pivot_err = 0;
     __syncthreads();
 
+    // Three workgroup barriers per pivot: wave 0 alone runs [record previous pivot -> loop head -> search
+    // + set-up] while the other waves wait at the barrier below; the pivot functions hold the other two
+    // (after the line updates, after the finalize step).
     for (;;) {
-        // ---- loop head: done / stop / error?
-        if (tid == 0) {
-            if (g_pivot_err) sm->exit_code = ST_ERROR;
-            else if (sm->rank + sm->rankdef >= m) sm->exit_code = ST_DONE;
-            else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) sm->exit_code = ST_STOPPED;
-            sm->need_search = sm->pc < 0;
-        }
-        __syncthreads();
-        if (sm->exit_code) break;
-        PROF_STAMP(0);
-
-        // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
-        // `need_search` is decided by thread 0 before the barrier above: sm->pc itself is rewritten by
-        // the searching wave, so testing it here would race with slower waves.
-        // The searching wave also lays out the pivot (positions, L/U room check, and for the two
-        // common pivot kinds the LDS working set of k_pivot_fast.hip) before the barrier.
         if (w == 0) {
-            bool handled = false;
-            if (sm->need_search) {
-                if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast(D, sm);
-                if (!handled) {
-                    if (D.search_rows == 0) markowitz_wave(D, sm);
-                    else if (lane == 0) markowitz_serial(D, sm);
-                    wave_mem_sync();
-                }
+            // ---- loop head: done / stop / error?
+            if (lane == 0) {
+                if (g_pivot_err) sm->exit_code = ST_ERROR;
+                else if (sm->rank + sm->rankdef >= m) sm->exit_code = ST_DONE;
+                else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) sm->exit_code = ST_STOPPED;
+                sm->need_search = sm->pc < 0;
+                sm->head_exit = sm->exit_code;
             }
-            if (!handled && lane == 0) setup_pivot_general(D, sm);
+            wave_mem_sync();
+            PROF_STAMP(0);
+            // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
+            // The searching wave also lays out the pivot (positions, L/U room check, and for the two
+            // common pivot kinds the LDS working set of k_pivot_fast.hip) before the barrier.
+            if (!sm->head_exit) {
+                bool handled = false;
+                if (sm->need_search) {
+                    if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast(D, sm);
+                    if (!handled) {
+                        if (D.search_rows == 0) markowitz_wave(D, sm);
+                        else if (lane == 0) markowitz_serial(D, sm);
+                        wave_mem_sync();
+                    }
+                }
+                if (!handled && lane == 0) setup_pivot_general(D, sm);
+            }
         }
         __syncthreads();
+        if (sm->head_exit) break;
         const int pr = sm->pr, pc = sm->pc;
         if (pc < 0) { // no pivot found: the reference asserts (factorize_bump.rs:22)
             if (tid == 0) {
@@ -1244,6 +1255,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             __syncthreads(); // every thread has read sm->pr / sm->pc before thread 0 rewrites them
             if (tid == 0) {
                 list_remove1(D.cflink, D.cblink, pc);
+                sm->fa.qN = 0;
                 sm->pc = -1;
                 sm->rankdef++;
                 sm->kinds[5]++;
@@ -1283,6 +1295,14 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
                 sm->prof[13] += sm->pstamp[13] - sm->pstamp[12]; // column metadata + column hash
                 sm->prof[14] += sm->pstamp[14] - sm->pstamp[13]; // row hash + room sums
                 sm->prof[15] += sm->pstamp[1] - sm->pstamp[14]; // barrier after the search
+                // inside "candidate entries + row metadata": loads drained separately (PROF_WAIT)
+                sm->prof[16] += sm->pstamp[17] - sm->pstamp[16]; // entries: address arithmetic + load + drain
+                sm->prof[17] += sm->pstamp[18] - sm->pstamp[17]; // row metadata: load + drain
+                sm->prof[18] += sm->pstamp[10] - sm->pstamp[18]; // LDS stores + costs
+                // inside the walk
+                sm->prof[19] += sm->pstamp[19] - sm->pstamp[8];  // list heads loaded
+                sm->prof[20] += sm->pstamp[20] - sm->pstamp[19]; // first candidate's link + metadata loaded
+                sm->prof[21] += 1;
             }
         }
 #endif
@@ -1296,6 +1316,8 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
                     if (D.colmax[j] == 0.0 || D.colmax[j] < D.abstol) remove_col_serial(D, sm, j);
                 }
             }
+            // the candidate queue survives only pivots whose column set is in the LDS hash (k_pivot_fast.hip)
+            if (sm->fa.kind == 0 || sm->flag_small) sm->fa.qN = 0;
             sm->flops += (long long)(nz_col - 1) * (long long)(nz_row - 1);
             D.pinv[pr] = rank;
             D.qinv[pc] = rank;
@@ -1305,7 +1327,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             sm->pr = -1;
             sm->rank = rank + 1;
         }
-        __syncthreads();
+        // no barrier: the other waves touch nothing until the barrier that follows the next search
     }
 
     if (tid == 0) {
@@ -1324,9 +1346,9 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         S->factor_flops += sm->flops;
         S->nexpand += sm->nexpand;
         S->d3_hits += sm->d3;
-        for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
+        for (int k = 0; k < 12; k++) S->npivot_kind[k] += sm->kinds[k];
 #ifdef BLU_PROFILE
-        for (int k = 0; k < 16; k++) S->prof[k] += sm->prof[k];
+        for (int k = 0; k < 24; k++) S->prof[k] += sm->prof[k];
 #endif
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }

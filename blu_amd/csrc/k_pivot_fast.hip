@@ -208,38 +208,50 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
 }
 
 // ------------------------------------------------------------------------------------------------
-// Flattened Markowitz search + pivot set-up, ONE wave.  Returns false if the shape is outside what
-// this path handles (nothing has been modified then; the caller runs the general search).
-// On return true: sm->pr/pc set (pr = -1: empty column; pc = -1: error), and for a real pivot
-// sm->pcb/prb/nzc/nzr, the L/U room check (sm->exit_code) and fa->kind.
+// Flattened Markowitz search + pivot set-up, ONE wave, in three parts so that the first two can run
+// EARLY -- beside the finalize work of the previous pivot -- on the list state as it was BEFORE that
+// pivot's list update:
+//   mk_walk   the first K columns in list order (with `skip`: members of the previous pivot's column
+//             set are passed over -- they are leaving these lists), their (begin,len,max)
+//   mk_stage  all candidate entries + the (begin,len,cap) of their rows -> LDS, cost of every eligible
+//             entry, per-lane best
+//   mk_pick   lexicographic wave min (cost, flat position) == the reference's sequential strict-<
+//             scan (markowitz.rs:80-122); pivot row/column and the metadata of every line they touch ->
+//             LDS, hash sets, room checks, fa->kind
+// mk_walk returns: 0 candidates found, 1 empty column chosen (pr = -1), 2 error, 3 shape not handled
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
+__device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
 {
     const int lane = lane_id();
     const int m = D.m;
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
-    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost*256 + position must fit 64 bits)
-    if (lane == 0) fa->kind = 0;
-
-    PROF_STAMP(8);
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) return 3; // (cost*256 + position must fit 64 bits)
+    if (lane == 0) {
+        sm->kinds[7]++;
+        fa->qN = 0;
+    }
     const int h0 = D.cflink[m];
     if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
         if (lane == 0) {
             sm->pc = h0;
             sm->pr = -1;
         }
-        return true;
+        return 1;
     }
-    // ---- first K columns in list order, starting at the first non-empty count list >= min_colnz
     int ncand = 0, total = 0;
     int nz = sm->min_colnz;
+    int lastfl = -1, lastnz = 0;
     bool bad = false;
     while (ncand < K && nz <= m && !bad) {
         const int k = nz + lane;
         const int h = k <= m ? D.cflink[m + k] : m + k;
         unsigned long long ne = __ballot(k <= m && h != m + k);
+        if (ncand == 0) {
+            PROF_WAIT();
+            PROF_STAMP(19);
+        }
         while (ne && ncand < K && !bad) {
             const int b = __ffsll((long long)ne) - 1;
             ne &= ne - 1;
@@ -250,6 +262,10 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
                 const int fl = D.cflink[j];
                 const int cb = D.cbeg[j], cl = D.clen[j];
                 const double cmx = D.colmax[j];
+                if (ncand == 0) {
+                    PROF_WAIT();
+                    PROF_STAMP(20);
+                }
                 if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
                     bad = true;
                     break;
@@ -261,33 +277,211 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
                     fa->cL[ncand] = cl;
                     fa->cMx[ncand] = cmx;
                     fa->cOff[ncand] = total;
+                    if (BLU_QUEUE) { // the walk also (re)starts the candidate queue
+                        fa->qJ[ncand] = j;
+                        fa->qNz[ncand] = znz;
+                        fa->qB[ncand] = cb;
+                        fa->qL[ncand] = cl;
+                        fa->qMx[ncand] = cmx;
+                    }
                 }
                 total += cl;
                 ncand++;
+                lastfl = fl;
+                lastnz = znz;
                 j = fl;
             }
         }
         nz += 64;
     }
-    PROF_STAMP(9); // candidates walked (list heads + up to K link/meta loads)
     if (bad || ncand == 0) { // reference: assert / D2 / "no pivot found" assert
         DEV_CHECK(S, false);
         if (lane == 0) {
             sm->pc = -1;
             sm->pr = -1;
         }
-        return true;
+        return 2;
     }
-    if (total > STGMAX) return false;
-    if (lane == 0) fa->cOff[ncand] = total;
+    if (lane == 0) {
+        fa->cOff[ncand] = total;
+        fa->ncand = ncand;
+        if (BLU_QUEUE) {
+            fa->qN = ncand;
+            fa->qCont = lastfl; // >= m: end of list lastnz, as of this search
+            fa->qContNz = lastnz;
+        }
+    }
     wave_mem_sync();
+    if (total > STGMAX) return 3;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Candidate queue.  The walk above costs one dependent memory round trip per candidate; but the
+// leading columns of the count lists change little from pivot to pivot: the columns of the last pivot
+// row leave (they are re-appended at the tails of their new lists), everything else keeps its place.
+// So the first columns in search order are kept in LDS across pivots:
+//   * after a pivot handled by the paths of this file, q_prepare drops the members of that pivot's
+//     column set from the queue; the rest is still a prefix of the search order provided no moved column
+//     re-entered before the queue's end, i.e. min(new counts) >= count of the last queued column
+//     (an equal count is appended behind every older member of that list);
+//   * any other event (general pivot paths, removed or empty columns, relaunch) empties the queue and
+//     the next search walks the lists;
+//   * the queue is topped up while the search waits for its own loads (QRef below): one element per
+//     step, read through the successor link of the last queued column.
+// The unmoved columns' (begin, len, max) cannot change, so no queued value goes stale.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int q_prepare(const DevG &D, Sm *sm)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (!BLU_QUEUE) return 2;
+    const int n = fa->qN;
+    if (n < K || K < 1 || K > KCMAX) {
+        if (lane == 0) sm->kinds[n == 0 ? 8 : 9]++;
+        return 2;
+    }
+    const int j = lane < n ? fa->qJ[lane] : -1;
+    const int jnz = lane < n ? fa->qNz[lane] : 0, jb = lane < n ? fa->qB[lane] : 0, jl = lane < n ? fa->qL[lane] : 0;
+    const double jmx = lane < n ? fa->qMx[lane] : 0.0;
+    const bool keep = lane < n && !hcol_has(fa, j);
+    const unsigned long long kb = __ballot(keep);
+    const int nn = __popcll(kb);
+    if (nn < K) {
+        if (lane == 0) sm->kinds[10]++;
+        return 2;
+    }
+    const int lastl = 63 - __clzll((long long)kb);
+    if (fa->qMinNew < __shfl(jnz, lastl)) {
+        if (lane == 0) sm->kinds[11]++;
+        return 2;
+    }
+    const int cont = fa->qCont;
+    // the known successor may be the head of a LATER list (qContNz > count of the last queued column):
+    // a column re-appended to a list in between would come first
+    const bool contok = lastl == n - 1 && cont >= 0 && cont < D.m && !hcol_has(fa, cont) && fa->qMinNew >= fa->qContNz;
+    wave_mem_sync();
+    const int d = __popcll(kb & lanes_below(lane));
+    if (keep) {
+        fa->qJ[d] = j;
+        fa->qNz[d] = jnz;
+        fa->qB[d] = jb;
+        fa->qL[d] = jl;
+        fa->qMx[d] = jmx;
+    }
+    // the first K become this search's candidates
+    if (keep && d < K) {
+        fa->cJ[d] = j;
+        fa->cNz[d] = jnz;
+        fa->cB[d] = jb;
+        fa->cL[d] = jl;
+        fa->cMx[d] = jmx;
+    }
+    wave_mem_sync();
+    if (lane == 0) {
+        int tot = 0;
+        for (int i = 0; i < K; i++) {
+            fa->cOff[i] = tot;
+            tot += fa->cL[i];
+        }
+        fa->cOff[K] = tot;
+        fa->ncand = K;
+        fa->qN = nn;
+        if (!contok) fa->qCont = -1;
+    }
+    wave_mem_sync();
+    if (fa->cOff[K] > STGMAX) return 3;
+    return 0;
+}
+
+// one pending top-up load of the queue; all members are wave-uniform except h
+struct QRef {
+    int kind; // 0 none, 1 (count, begin, len, max, link) of column x, 2 successor link of the last column, 3 list heads
+    int x, nz, fl, cb, cl, h;
+    double mx;
+};
+__device__ __forceinline__ void qref_issue(const DevG &D, Fast *fa, QRef &r)
+{
+    r.kind = 0;
+    const int n = fa->qN, m = D.m;
+    if (!BLU_QUEUE || n <= 0 || n >= QMAX) return;
+    const int cont = fa->qCont;
+    if (cont >= 0 && cont < m) {
+        r.kind = 1;
+        r.x = cont;
+        r.nz = fa->qContNz;
+        r.fl = D.cflink[cont];
+        r.cb = D.cbeg[cont];
+        r.cl = D.clen[cont];
+        r.mx = D.colmax[cont];
+    } else if (cont < 0) {
+        r.kind = 2;
+        r.nz = fa->qNz[n - 1];
+        r.fl = D.cflink[fa->qJ[n - 1]];
+    } else { // end of list qContNz: first element of the next non-empty list within 64 counts
+        r.kind = 3;
+        r.nz = fa->qContNz + 1;
+        const int k = r.nz + lane_id();
+        r.h = k <= m ? D.cflink[m + k] : m + k;
+    }
+}
+__device__ __forceinline__ void qref_consume(const DevG &D, Fast *fa, QRef &r)
+{
+    const int lane = lane_id(), m = D.m;
+    if (r.kind == 0) return;
+    if (r.kind == 1) {
+        // a column that fails these checks stops the top-up; the list walk raises the error when it gets there
+        const bool good = r.cl == r.nz && r.mx != 0.0 && r.mx >= D.abstol;
+        if (lane == 0) {
+            if (good) {
+                const int n = fa->qN;
+                fa->qJ[n] = r.x;
+                fa->qNz[n] = r.nz;
+                fa->qB[n] = r.cb;
+                fa->qL[n] = r.cl;
+                fa->qMx[n] = r.mx;
+                fa->qN = n + 1;
+                fa->qCont = r.fl;
+                fa->qContNz = r.nz;
+            } else {
+                fa->qCont = -1;
+            }
+        }
+    } else if (r.kind == 2) {
+        if (lane == 0) {
+            fa->qCont = r.fl;
+            fa->qContNz = r.nz;
+        }
+    } else {
+        const int k = r.nz + lane;
+        const unsigned long long ne = __ballot(k <= m && r.h != m + k);
+        if (ne) {
+            const int b = __ffsll((long long)ne) - 1;
+            const int x = __shfl(r.h, b);
+            if (lane == 0) {
+                fa->qCont = x;
+                fa->qContNz = r.nz + b;
+            }
+        } else if (lane == 0) {
+            fa->qCont = -1;
+        }
+    }
+    r.kind = 0;
+    wave_mem_sync();
+}
+
+__device__ __forceinline__ void mk_stage(const DevG &D, Sm *sm, long long &mcb, int &fb)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    const int ncand = fa->ncand, total = fa->cOff[ncand];
     const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
               off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
-
-    // ---- all candidate entries at once: cost (nz-1)(rownz-1) of every eligible entry
     const long long BIG = 0x7fffffffffffffffLL;
-    long long mcb = BIG;
-    int fb = 0x7fffffff;
+    mcb = BIG;
+    fb = 0x7fffffff;
+    PROF_STAMP(16);
     for (int base = 0; base < total; base += 64) {
         const int f = base + lane;
         if (f < total) {
@@ -296,7 +490,15 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
             const int pos = fa->cB[c] + e;
             const int idx = D.cidx[pos];
             const double val = D.cval[pos];
+            if (base == 0) {
+                PROF_WAIT();
+                PROF_STAMP(17);
+            }
             const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+            if (base == 0) {
+                PROF_WAIT();
+                PROF_STAMP(18);
+            }
             fa->sI[f] = idx;
             fa->sV[f] = val;
             fa->sB[f] = rb;
@@ -314,9 +516,19 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
             }
         }
     }
-    PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
-    // lexicographic min over (cost, flat position) in ONE LDS atomic: key = cost * 256 + position
-    // (position < STGMAX <= 256, cost < 2^55); the first-seen entry wins ties (markowitz.rs:105)
+}
+
+__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, QRef &qr)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int ncand = fa->ncand;
+    const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
+              off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
+    const long long BIG = 0x7fffffffffffffffLL;
+    if (lane == 0) fa->kind = 0;
+    // key = cost * 256 + position (position < STGMAX <= 256, cost < 2^55); first-seen entry wins ties
     const long long bestkey = wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
     wave_mem_sync();
     if (bestkey == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
@@ -325,7 +537,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
             sm->pc = -1;
             sm->pr = -1;
         }
-        return true;
+        return;
     }
     const int fsel = (int)(bestkey & 255LL);
     const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
@@ -360,7 +572,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
         if (nzc == 1) kind = 2;
         else if (nzc >= 3 && nzc <= PCMAX) kind = 1;
     }
-    if (kind == 0) return true;
+    if (kind == 0) return;
 
     // ---- pivot column into LDS; kind 1: pivot swapped to the front (pivot.rs:169-170)
     const int coff = fa->cOff[csel];
@@ -385,9 +597,11 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
     if (wpos < 0) {
         DEV_CHECK(S, false);
         if (lane == 0) sm->pc = -1;
-        return true;
+        return;
     }
     PROF_STAMP(12); // pivot column copied, pivot row loaded
+    qref_consume(D, fa, qr); // (its loads were issued before those of the pivot row: no extra wait)
+    qref_issue(D, fa, qr);
     for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
     for (int s = lane; s < HCOL; s += 64) fa->hColK[s] = -1;
     long long gc = 0, gr = 0;
@@ -410,6 +624,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
         }
     }
     PROF_STAMP(13); // line metadata of the pivot row's columns loaded, column hash built
+    qref_consume(D, fa, qr);
     if (kind == 1) {
         for (int p = 1 + lane; p < nzc; p += 64) {
             hrow_insert(fa, fa->pcI[p], p);
@@ -426,6 +641,76 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
         fa->where = wpos;
     }
     PROF_STAMP(14);
+}
+
+// the complete search on the current list state.  Returns false if the shape is outside what this path
+// handles (nothing has been modified then; the caller runs the general search).
+__device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
+{
+    Fast *fa = &sm->fa;
+    if (lane_id() == 0) fa->kind = 0;
+    PROF_STAMP(8);
+    int r = q_prepare(D, sm);
+    if (r == 2) {
+        r = mk_walk(D, sm);
+    } else {
+        if (lane_id() == 0) sm->kinds[6]++;
+#ifdef BLU_QCHECK
+        // self-checking build (`make qcheck`): every answer of the queue is compared with a walk of the
+        // lists; the queue itself is put back afterwards so that its evolution is the product's
+        const int lane = lane_id(), K = D.maxsearch;
+        const int sJ = lane < QMAX ? fa->qJ[lane] : 0, sNz = lane < QMAX ? fa->qNz[lane] : 0, sB = lane < QMAX ? fa->qB[lane] : 0,
+                  sL = lane < QMAX ? fa->qL[lane] : 0;
+        const double sMx = lane < QMAX ? fa->qMx[lane] : 0.0;
+        const int sN = fa->qN, sCont = fa->qCont, sContNz = fa->qContNz;
+        const int myc = lane < K ? fa->cJ[lane] : -1;
+        wave_mem_sync();
+        const int r2 = mk_walk(D, sm);
+        const bool same = r2 == r && (lane >= K || fa->cJ[lane] == myc);
+        if (__ballot(!same)) {
+            if (lane == 0 && D.s->prof[0] == 0) { // first mismatch: what the queue said / what the lists say
+                long long *P = D.s->prof;
+                P[0] = 1 + sm->rank;
+                P[1] = r * 10 + r2;
+                P[2] = sN;
+                P[3] = fa->qMinNew;
+                P[4] = sCont;
+                P[5] = sContNz;
+                P[6] = sm->min_colnz;
+                for (int i = 0; i < 3; i++) P[7 + i] = fa->cJ[i] * 1000LL + fa->cNz[i];
+            }
+            if (lane < 3) D.s->prof[10 + lane] = myc * 1000LL + sNz; // (sNz of the purged queue's first entries)
+            DEV_CHECK(D.s, false);
+        }
+        wave_mem_sync();
+        if (lane < QMAX) {
+            fa->qJ[lane] = sJ;
+            fa->qNz[lane] = sNz;
+            fa->qB[lane] = sB;
+            fa->qL[lane] = sL;
+            fa->qMx[lane] = sMx;
+        }
+        if (lane == 0) {
+            fa->qN = sN;
+            fa->qCont = sCont;
+            fa->qContNz = sContNz;
+            sm->kinds[7]--;
+        }
+        wave_mem_sync();
+#endif
+    }
+    PROF_STAMP(9); // candidates known (from the queue, or list heads + up to K link/meta loads)
+    if (r == 3) return false;
+    if (r != 0) return true; // empty column chosen, or error raised
+    QRef qr;
+    qref_issue(D, fa, qr); // queue top-ups ride on the waits of the search's own loads
+    long long mcb;
+    int fb;
+    mk_stage(D, sm, mcb, fb);
+    PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
+    qref_consume(D, fa, qr);
+    qref_issue(D, fa, qr);
+    mk_pick(D, sm, mcb, fb, qr);
     return true;
 }
 
@@ -646,6 +931,17 @@ __device__ __forceinline__ void fast_fixrow(const DevG &D, Sm *sm, int p)
     }
 }
 
+// smallest key >= 0 (new count of a moved column), for the queue's validity test
+__device__ __forceinline__ int wave_min_key(const int *keys, int n, int big)
+{
+    int v = big;
+    for (int c = lane_id(); c < n; c += 64) {
+        const int k = keys[c];
+        if (k >= 0 && k < v) v = k;
+    }
+    return wave_min_i(v);
+}
+
 // U row from the LDS copies (pivot.rs:306-312): slots q0..q1 of the pivot row except skipq
 __device__ __forceinline__ void fast_write_u(const DevG &D, Sm *sm, int q0, int q1, int skipq)
 {
@@ -757,6 +1053,10 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm)
             D.rlen[pr] = 0;
             sm->kinds[3]++;
         }
+        if (BLU_QUEUE) {
+            const int mnew = wave_min_key(fa->tNew + 1, rnz1, m + 2);
+            if (lane == 0) fa->qMinNew = mnew;
+        }
         PROF_STAMP(6);
     }
     if (w == 1 % nw) fast_write_l(D, sm);
@@ -836,6 +1136,10 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm)
             D.clen[pc] = 0;
             D.rlen[pr] = 0;
             sm->kinds[1]++;
+        }
+        if (BLU_QUEUE) {
+            const int mnew = wave_min_key(fa->tNew, rl, m + 2);
+            if (lane == 0) fa->qMinNew = mnew;
         }
     }
     if (w == 1 % nw) {

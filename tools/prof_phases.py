@@ -12,9 +12,13 @@ if len(sys.argv) > 2:
     h.dbg_set_block(int(sys.argv[2]))
 for rep in range(2):
     st = h.factorize(cp[:-1], cp[1:], ri, v)
-p = [h.stat(60 + k) for k in range(16)]
+p = [h.stat(60 + k) for k in range(24)]
 tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
 tot = sum(p[:4])
+print("searches served from the candidate queue: %d, list walks: %d (queue empty %d, short %d, short after purge %d, re-entry %d)" % tuple(h.stat(k) for k in (48, 49, 44, 45, 46, 47)))
+if tot == 0:
+    print("status", st, "t_pivot %.1f ms (not a diagnostic build: no phase ticks)" % (1e3 * tp))
+    sys.exit(0)
 print("status", st, "t_pivot %.1f ms" % (1e3 * tp), "ticks total %.3g -> %.2f GHz-equivalent" % (tot, tot / tp / 1e9))
 n1, n2, n3 = p[4], p[5], p[6]
 f = tp / tot * 1e6  # us per tick
@@ -24,3 +28,6 @@ print("fast scol   : n=%d %.2f us each (%.0f%%)" % (n2, p[2] * f / max(1, n2), 1
 print("general     : n=%d %.2f us each (%.0f%%)" % (n3, p[3] * f / max(1, n3), 100 * p[3] / tot))
 names = ["enter", "walk lists", "entries+rowmeta+cost", "argmin", "pivot col->LDS, row load", "col metadata+hash", "row hash+sums", "barrier"]
 print("search stages (us per fast pivot): " + " | ".join("%s %.2f" % (nm, p[8 + k] * f / max(1, n1 + n2)) for k, nm in enumerate(names)))
+nf = max(1, p[21])
+print("inside (cycles per fast pivot): entries addr+load+drain %.0f | row metadata load+drain %.0f | LDS stores+costs %.0f || list heads %.0f | first candidate link+meta %.0f"
+      % (p[16] / nf, p[17] / nf, p[18] / nf, p[19] / nf, p[20] / nf))
