@@ -61,7 +61,7 @@ struct Scalars {
     double min_pivot, max_pivot;
     double onenorm, infnorm;
     double norm_l, norm_u, normest_l_inv, normest_u_inv, condest_l, condest_u, residual_test;
-    long long prof[24];    // diagnostic build only (-DBLU_PROFILE): shader-clock ticks per phase of the pivot loop
+    long long prof[48];    // diagnostic build only (-DBLU_PROFILE): shader-clock ticks per phase of the pivot loop
 };
 
 // Scalar members of the descriptor: dimensions, parameters (public fields of struct LU,

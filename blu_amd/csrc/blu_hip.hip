@@ -336,6 +336,8 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 58: return (double)s.status;
     case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:
     case 76: case 77: case 78: case 79: case 80: case 81: case 82: case 83:
+    case 84: case 85: case 86: case 87: case 88: case 89: case 90: case 91:
+    case 92: case 93: case 94: case 95: case 96: case 97: case 98: case 99: case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107:
         return (double)s.prof[key - 60]; // diagnostic build only
     default: return NAN;
     }

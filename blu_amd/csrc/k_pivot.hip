@@ -35,9 +35,15 @@ __shared__ int g_pivot_err;
 // Diagnostic build (-DBLU_PROFILE, `make prof`): thread 0 stamps the shader clock at phase boundaries
 // of the pivot loop.  The product build contains no stamps.
 #ifdef BLU_PROFILE
+__shared__ long long g_pstamp[48];
 #define PROF_STAMP(k)                                                      \
     do {                                                                   \
-        if (threadIdx.x == 0) sm->pstamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0) g_pstamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+// PROF_STAMP_L0: the same from code that a single wave other than wave 0 runs
+#define PROF_STAMP_L0(k)                                                           \
+    do {                                                                           \
+        if (lane_id() == 0) g_pstamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 // PROF_WAIT: drain this wave's vector-memory operations, so that the stamp that follows separates
 // "loads issued + arrived" from the arithmetic behind them (changes the timing a little: diagnostic only)
@@ -46,22 +52,31 @@ __shared__ int g_pivot_err;
 #define PROF_STAMP(k) \
     do {              \
     } while (0)
+#define PROF_STAMP_L0(k) \
+    do {                 \
+    } while (0)
 #define PROF_WAIT() \
     do {            \
     } while (0)
 #endif
 
-struct Sm {
-    Fast fa;
-    long long prof[24], pstamp[24];
-    int pr, pc;
+struct alignas(16) Sm {
+    Fast fa; // begins with kind, where, anycancel, ncand
+    // what every wave needs right after the search barrier sits in 16-byte groups (with fa's first four
+    // ints): three LDS reads issued together instead of a chain of read -> branch -> read
+    struct alignas(16) {
+        int pr, pc, exit_code, head_exit;
+    };
+    struct alignas(16) {
+        int nzc, nzr, pcb, prb;
+    };
+    long long prof[48];
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
-    int nzc, nzr, pcb, prb;
-    int exit_code, need;
+    int need;
     int flag_small;
     int other_row, where, ncancel, nfill;
-    int stop_at, need_search, head_exit;
+    int stop_at, need_search;
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
     long long kinds[12];
@@ -1203,9 +1218,10 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->fa.qN = 0;
         sm->fa.kind = 0;
         for (int k = 0; k < 12; k++) sm->kinds[k] = 0;
-        for (int k = 0; k < 24; k++) sm->prof[k] = 0;
+        for (int k = 0; k < 48; k++) sm->prof[k] = 0;
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
+    for (int k = tid; k < 2 * KGMAX; k += blockDim.x) sm->fa.kg[0][k] = 0ull;
     if (tid == 0) g_pivot_err = 0;
     __syncthreads();
 
@@ -1241,8 +1257,11 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             }
         }
         __syncthreads();
-        if (sm->head_exit) break;
-        const int pr = sm->pr, pc = sm->pc;
+        const int4 dA = *reinterpret_cast<const int4 *>(&sm->pr);      // pr, pc, exit_code, head_exit
+        const int4 dB = *reinterpret_cast<const int4 *>(&sm->nzc);     // nzc, nzr, pcb, prb
+        const int4 dC = *reinterpret_cast<const int4 *>(&sm->fa.kind); // kind, where, anycancel, ncand
+        if (dA.w) break;
+        const int pr = dA.x, pc = dA.y;
         if (pc < 0) { // no pivot found: the reference asserts (factorize_bump.rs:22)
             if (tid == 0) {
                 DEV_CHECK(S, false);
@@ -1265,12 +1284,13 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         }
 
         // ---- pivot(): the room check of pivot.rs:70-81 was made by the searching wave; dispatch (:84-94)
-        if (sm->exit_code) break;
+        if (dA.z) break;
         PROF_STAMP(1);
-        const int nz_col = sm->nzc, nz_row = sm->nzr;
+        const int nz_col = dB.x, nz_row = dB.y;
+        const int kind = dC.x;
         bool ok = true;
-        if (sm->fa.kind == 1) fast_small(D, sm);
-        else if (sm->fa.kind == 2) fast_scol(D, sm);
+        if (kind == 1) fast_small(D, sm, pr, pc, nz_col, nz_row);
+        else if (kind == 2) fast_scol(D, sm, pr, pc, nz_row, dC.y);
         else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
         else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
         else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
@@ -1280,29 +1300,52 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 #ifdef BLU_PROFILE
         if (tid == 0) {
             const int kk = sm->fa.kind == 1 ? 1 : (sm->fa.kind == 2 ? 2 : 3);
-            sm->prof[0] += sm->pstamp[1] - sm->pstamp[0];  // search + set-up (incl. barrier)
-            sm->prof[kk] += sm->pstamp[2] - sm->pstamp[1]; // pivot: 1 fast small, 2 fast singleton col, 3 general paths
+            sm->prof[0] += g_pstamp[1] - g_pstamp[0];  // search + set-up (incl. barrier)
+            sm->prof[kk] += g_pstamp[2] - g_pstamp[1]; // pivot: 1 fast small, 2 fast singleton col, 3 general paths
             sm->prof[3 + kk] += 1;                         // counts at 4,5,6
             if (kk == 1) {
-                sm->prof[7] += sm->pstamp[3] - sm->pstamp[1];   // fast small: line updates (rest = finalize)
+                sm->prof[7] += g_pstamp[3] - g_pstamp[1];   // fast small: line updates (rest = finalize)
+                // the finalize step, relative to the barrier after the line updates (stamp 3)
+                sm->prof[22] += g_pstamp[6] - g_pstamp[3];   // wave 0: U row written
+                sm->prof[23] += g_pstamp[24] - g_pstamp[3];  // wave 1: L column written
+                sm->prof[24] += g_pstamp[25] - g_pstamp[3];  // wave 2: list update entered
+                sm->prof[25] += g_pstamp[26] - g_pstamp[25]; //   links + tails loaded
+                sm->prof[26] += g_pstamp[27] - g_pstamp[26]; //   runs resolved (LDS pointer jumping)
+                sm->prof[27] += g_pstamp[28] - g_pstamp[27]; //   stores issued
+                sm->prof[30] += g_pstamp[30] - g_pstamp[27]; //     of which: runs unlinked
+                sm->prof[31] += g_pstamp[31] - g_pstamp[30]; //     tails resolved, same-key groups found
+                sm->prof[28] += g_pstamp[29] - g_pstamp[28]; //   stores drained
+                sm->prof[29] += g_pstamp[2] - g_pstamp[29];  // list wave done -> all waves past the last barrier
+                // the line updates, seen by wave 1 (its first three tasks; the first is a column)
+                sm->prof[32] += sm->nzr - 1;                 // tasks: columns
+                sm->prof[33] += sm->nzc - 1;                 //        rows
+                sm->prof[34] += g_pstamp[33] - g_pstamp[1];  // loads of the first three tasks issued
+                sm->prof[35] += g_pstamp[34] - g_pstamp[33]; // ... arrived
+                sm->prof[36] += g_pstamp[35] - g_pstamp[34]; // first task done
+                sm->prof[37] += g_pstamp[36] - g_pstamp[35]; // second task done
+                sm->prof[38] += g_pstamp[37] - g_pstamp[36]; // third task done
+                sm->prof[39] += g_pstamp[38] - g_pstamp[37]; // all of wave 1's tasks done, stores drained
+                sm->prof[40] += g_pstamp[3] - g_pstamp[38];  // ... until every wave is past the barrier
             }
             if (kk != 3) { // stages of the flattened search (stamps 8..14 set inside markowitz_fast)
-                sm->prof[8] += sm->pstamp[8] - sm->pstamp[0];   // head barrier -> search entered
-                sm->prof[9] += sm->pstamp[9] - sm->pstamp[8];   // walk: list heads + K link/meta loads
-                sm->prof[10] += sm->pstamp[10] - sm->pstamp[9]; // candidate entries + row metadata, costs
-                sm->prof[11] += sm->pstamp[11] - sm->pstamp[10]; // argmin
-                sm->prof[12] += sm->pstamp[12] - sm->pstamp[11]; // pivot column to LDS + pivot row load
-                sm->prof[13] += sm->pstamp[13] - sm->pstamp[12]; // column metadata + column hash
-                sm->prof[14] += sm->pstamp[14] - sm->pstamp[13]; // row hash + room sums
-                sm->prof[15] += sm->pstamp[1] - sm->pstamp[14]; // barrier after the search
+                sm->prof[8] += g_pstamp[8] - g_pstamp[0];   // head barrier -> search entered
+                sm->prof[9] += g_pstamp[9] - g_pstamp[8];   // walk: list heads + K link/meta loads
+                sm->prof[10] += g_pstamp[10] - g_pstamp[9]; // candidate entries + row metadata, costs
+                sm->prof[11] += g_pstamp[11] - g_pstamp[10]; // argmin
+                sm->prof[12] += g_pstamp[12] - g_pstamp[11]; // pivot column to LDS + pivot row load
+                sm->prof[13] += g_pstamp[13] - g_pstamp[12]; // column metadata + column hash
+                sm->prof[14] += g_pstamp[14] - g_pstamp[13]; // row hash + room sums
+                sm->prof[15] += g_pstamp[1] - g_pstamp[14]; // barrier after the search
                 // inside "candidate entries + row metadata": loads drained separately (PROF_WAIT)
-                sm->prof[16] += sm->pstamp[17] - sm->pstamp[16]; // entries: address arithmetic + load + drain
-                sm->prof[17] += sm->pstamp[18] - sm->pstamp[17]; // row metadata: load + drain
-                sm->prof[18] += sm->pstamp[10] - sm->pstamp[18]; // LDS stores + costs
-                // inside the walk
-                sm->prof[19] += sm->pstamp[19] - sm->pstamp[8];  // list heads loaded
-                sm->prof[20] += sm->pstamp[20] - sm->pstamp[19]; // first candidate's link + metadata loaded
-                sm->prof[21] += 1;
+                if (g_pstamp[16] > g_pstamp[8]) { // (not a column-singleton search: those take mk_express)
+                    sm->prof[16] += g_pstamp[17] - g_pstamp[16]; // entries: address arithmetic + load + drain
+                    sm->prof[17] += g_pstamp[18] - g_pstamp[17]; // row metadata: load + drain
+                    sm->prof[18] += g_pstamp[10] - g_pstamp[18]; // LDS stores + costs
+                    // inside the walk
+                    sm->prof[19] += g_pstamp[19] - g_pstamp[8];  // list heads loaded
+                    sm->prof[20] += g_pstamp[20] - g_pstamp[19]; // first candidate's link + metadata loaded
+                    sm->prof[21] += 1;
+                }
             }
         }
 #endif
@@ -1348,7 +1391,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         S->d3_hits += sm->d3;
         for (int k = 0; k < 12; k++) S->npivot_kind[k] += sm->kinds[k];
 #ifdef BLU_PROFILE
-        for (int k = 0; k < 24; k++) S->prof[k] += sm->prof[k];
+        for (int k = 0; k < 48; k++) S->prof[k] += sm->prof[k];
 #endif
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }

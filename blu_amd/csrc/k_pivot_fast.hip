@@ -40,32 +40,83 @@ __device__ __forceinline__ int hrow_lookup(const Fast *f, int k)
         s = (s + 1) & (HROW - 1);
     }
 }
-__device__ __forceinline__ void hcol_insert(Fast *f, int k)
+__device__ __forceinline__ void hcol_insert(Fast *f, int k, int slot)
 {
-    unsigned s = hslot(k, 10);
+    unsigned s = hslot(k, HCOL_BITS);
+    const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)slot;
     for (;;) {
-        const int old = atomicCAS(&f->hColK[s], -1, k);
-        if (old == -1 || old == k) return;
+        const unsigned long long old = atomicCAS(&f->hCol[s], ~0ull, want);
+        if (old == ~0ull || (int)(old >> 32) == k) return;
         s = (s + 1) & (HCOL - 1);
     }
 }
 __device__ __forceinline__ bool hcol_has(const Fast *f, int k)
 {
-    unsigned s = hslot(k, 10);
+    unsigned s = hslot(k, HCOL_BITS);
     for (;;) {
-        const int kk = f->hColK[s];
-        if (kk == k) return true;
-        if (kk == -1) return false;
+        const unsigned long long x = f->hCol[s];
+        if ((int)(x >> 32) == k) return true;
+        if (x == ~0ull) return false;
         s = (s + 1) & (HCOL - 1);
     }
 }
+// Three look-ups at once in a table of (key << 32 | value) words: the probes of the three keys are
+// issued together, so the whole costs about one LDS round trip.  r = value, or -1 if the key is absent
+// (or its look-up not wanted).
+template <int BITS>
+__device__ __forceinline__ void hash_find3(const unsigned long long *H, int k1, int k2, int k3, bool w1, bool w2, bool w3, int &r1,
+                                           int &r2, int &r3)
+{
+    const unsigned mask = (1u << BITS) - 1u;
+    unsigned s1 = hslot(k1, BITS), s2 = hslot(k2, BITS), s3 = hslot(k3, BITS);
+    r1 = r2 = r3 = -1;
+    bool d1 = !w1, d2 = !w2, d3 = !w3;
+    while (!(d1 && d2 && d3)) {
+        const unsigned long long x1 = H[s1], x2 = H[s2], x3 = H[s3];
+        if (!d1) {
+            if ((int)(x1 >> 32) == k1) r1 = (int)(x1 & 0xffffffffull);
+            d1 = (int)(x1 >> 32) == k1 || x1 == ~0ull;
+            s1 = (s1 + 1) & mask;
+        }
+        if (!d2) {
+            if ((int)(x2 >> 32) == k2) r2 = (int)(x2 & 0xffffffffull);
+            d2 = (int)(x2 >> 32) == k2 || x2 == ~0ull;
+            s2 = (s2 + 1) & mask;
+        }
+        if (!d3) {
+            if ((int)(x3 >> 32) == k3) r3 = (int)(x3 & 0xffffffffull);
+            d3 = (int)(x3 >> 32) == k3 || x3 == ~0ull;
+            s3 = (s3 + 1) & mask;
+        }
+    }
+}
+// The element sets of the batched list moves: membership, and the lanes that handle three elements in
+// wave_list_move_batch_set (lane q holds elems[q]; lane n the element that is only removed).
 struct InHCol {
     const Fast *f;
+    int base, gone_slot; // elems = tJ + base; the pivot column sits at slot gone_slot of tJ
     __device__ __forceinline__ bool operator()(int e) const { return hcol_has(f, e); }
+    __device__ __forceinline__ int lane_of_slot(int s, int n) const { return s < 0 ? -1 : (s == gone_slot ? n : s - base); }
+    __device__ __forceinline__ void lanes_of(int e1, int e2, int e3, bool w1, bool w2, bool w3, int n, int &l1, int &l2, int &l3) const
+    {
+        int a, b, c;
+        hash_find3<HCOL_BITS>(f->hCol, e1, e2, e3, w1, w2, w3, a, b, c);
+        l1 = lane_of_slot(a, n);
+        l2 = lane_of_slot(b, n);
+        l3 = lane_of_slot(c, n);
+    }
 };
 struct InHRow {
     const Fast *f;
     __device__ __forceinline__ bool operator()(int e) const { return hrow_lookup(f, e) > 0; }
+    __device__ __forceinline__ void lanes_of(int e1, int e2, int e3, bool w1, bool w2, bool w3, int n, int &l1, int &l2, int &l3) const
+    {
+        int a, b, c; // position p >= 1 in the cached pivot column; elems = pcI + 1
+        hash_find3<HROW_BITS>(f->hRow, e1, e2, e3, w1, w2, w3, a, b, c);
+        l1 = a < 0 ? -1 : a - 1;
+        l2 = b < 0 ? -1 : b - 1;
+        l3 = c < 0 ? -1 : c - 1;
+    }
 };
 
 // Batched list_move (see wave_list_move_batch in k_pivot.hip) with the set of moved elements given
@@ -74,7 +125,8 @@ struct InHRow {
 // column / pivot row, list.rs:81-86 at the end of every pivot path).
 template <class InSet>
 __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
-                                        InSet inS, int big, int gone, int *scratch /* 320 ints of LDS */)
+                                        InSet inS, int big, int gone, int *scratch /* 320 ints of LDS */,
+                                        unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
 {
     const int lane = lane_id();
     int minkey = big;
@@ -98,64 +150,83 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
             t = blink[nelem + key];
             if (key > 0) minkey = key;
         }
+        // While the three loads are in flight: neighbours inside the new list = nearest lanes below /
+        // above with the same key.  One ballot per distinct key (a handful), the rest per lane.
+        unsigned long long mygrp = 0ull;
+        if (!__ballot(act && key >= KGMAX)) {
+            // small keys (new counts): the lanes of one key meet in an LDS word indexed by the key;
+            // the table is all-zero between calls
+            if (act) atomicOr(&kg[key], 1ull << lane);
+            wave_mem_sync();
+            if (act) {
+                mygrp = kg[key];
+                kg[key] = 0ull;
+            }
+        } else {
+            unsigned long long active = __ballot(act);
+            while (active) {
+                const int leader = __ffsll((long long)active) - 1;
+                const int k = __builtin_amdgcn_readlane(key, leader);
+                const unsigned long long grp = __ballot(act && key == k);
+                if (key == k) mygrp = grp;
+                active &= ~grp;
+            }
+        }
+        const unsigned long long below = mygrp & lanes_below(lane);
+        const unsigned long long above = lane < 63 ? mygrp & ~((2ull << lane) - 1ull) : 0ull;
+        const int prevl = below ? 63 - __clzll((long long)below) : -1;
+        const int nextl = above ? __ffsll((long long)above) - 1 : -1;
+        const int eprev = prevl >= 0 ? elems[prevl] : 0, enext = nextl >= 0 ? elems[nextl] : 0;
+        const int minall = wave_min_i(minkey);
         // Runs of adjacent moved elements are common (lines updated together were appended together),
-        // so "next unmoved element" / "previous unmoved element" are found by pointer jumping over the
-        // wave's own (element, pred, succ) triples in LDS, never by chasing links through memory.
-        int *bE = scratch, *bP = scratch + 64, *bN = scratch + 128, *bS = scratch + 192, *bQ = scratch + 256;
-        bE[lane] = unl ? e : -1;
-        bP[lane] = p;
-        bN[lane] = nx;
-        wave_mem_sync();
-        int sl = -1, pl = -1, tl = -1; // lanes holding my successor / my predecessor / the old tail of my new list
-        const int emine = unl ? e : -1;
-        for (int l2 = 0; l2 <= n; l2++) {
-            const int el = __builtin_amdgcn_readlane(emine, l2); // broadcast from a register: no LDS latency per step
-            if (el >= 0) {
-                if (el == nx) sl = l2;
-                if (el == p) pl = l2;
-                if (act && el == t) tl = l2;
+        // so "next unmoved element" / "previous unmoved element" are found by pointer doubling over the
+        // wave's own lanes, never by chasing links through memory.
+        PROF_WAIT();
+        PROF_STAMP_L0(26);
+        // lanes holding my successor / my predecessor / the old tail of my new list: three hash look-ups
+        // (a scan over the batch costs ~100 cycles per element in branches and cross-lane reads)
+        int sl, pl, tl;
+        inS.lanes_of(nx, p, t, unl, unl, act, n, sl, pl, tl);
+        const bool first = unl && pl < 0; // first of a run of moved neighbours
+        PROF_STAMP_L0(27);
+        // first unmoved element after / before every moved one, by pointer doubling over the lanes:
+        // (fs, sl) = (element after the stretch skipped so far, its lane if it is moved too)
+        int fs = nx, fp = p;
+        for (int round = 0; round < 7; round++) {
+            if (!__ballot((unl && sl >= 0) || (unl && pl >= 0))) break;
+            const int srcs = sl >= 0 ? sl : lane, srcp = pl >= 0 ? pl : lane;
+            const int fs2 = __shfl(fs, srcs), sl2 = __shfl(sl, srcs);
+            const int fp2 = __shfl(fp, srcp), pl2 = __shfl(pl, srcp);
+            if (sl >= 0) {
+                fs = fs2;
+                sl = sl2;
+            }
+            if (pl >= 0) {
+                fp = fp2;
+                pl = pl2;
             }
         }
-        bS[lane] = sl;
-        bQ[lane] = pl;
-        wave_mem_sync();
-        if (unl && pl < 0) { // first of a run: link its unmoved predecessor to the first unmoved successor
-            int cur = sl;
-            for (int guard = 0; cur >= 0 && guard <= n + 1; guard++) {
-                nx = bN[cur];
-                cur = bS[cur];
-            }
-            flink[p] = nx;
-            blink[nx] = p;
+        if (first) { // link the run's unmoved predecessor to its unmoved successor
+            flink[p] = fs;
+            blink[fs] = p;
         }
-        if (act) { // the old tail is being moved itself: the real tail is its nearest unmoved predecessor
-            int cur = tl;
-            for (int guard = 0; cur >= 0 && guard <= n + 1; guard++) {
-                t = bP[cur];
-                cur = bQ[cur];
-            }
-        }
+        PROF_STAMP_L0(30);
+        // the old tail is being moved itself: the real tail is its nearest unmoved predecessor
+        const int tfix = __shfl(fp, tl >= 0 ? tl : lane);
+        if (act && tl >= 0) t = tfix;
         if (lane == n && gone >= 0) { // list.rs:84-85: a removed element links to itself
             flink[gone] = gone;
             blink[gone] = gone;
         }
-        // neighbours inside the new list: nearest lanes below / above with the same key.  Every lane
-        // scans the (LDS-resident) key array; the reads are broadcasts, there is no per-key serial loop.
-        int prevl = -1, nextl = -1;
-        for (int l2 = 0; l2 < n; l2++) {
-            const int k2 = __builtin_amdgcn_readlane(key, l2);
-            if (k2 == key) {
-                if (l2 < lane) prevl = l2;
-                else if (l2 > lane && nextl < 0) nextl = l2;
-            }
-        }
+        PROF_STAMP_L0(31);
         if (act) {
-            blink[e] = prevl >= 0 ? elems[prevl] : t;
-            flink[e] = nextl >= 0 ? elems[nextl] : nelem + key;
+            blink[e] = prevl >= 0 ? eprev : t;
+            flink[e] = nextl >= 0 ? enext : nelem + key;
             if (prevl < 0) flink[t] = e;
             if (nextl < 0) blink[nelem + key] = e;
         }
-        return wave_min_i(minkey); // no drain here: the workgroup barrier that follows waits for the stores
+        PROF_STAMP_L0(28);
+        return minall; // no drain here: the workgroup barrier that follows waits for the stores
     }
     if (gone >= 0) { // long batches: unlink `gone` first, as the general path does
         if (lane == 0) list_remove1(flink, blink, gone);
@@ -518,7 +589,54 @@ __device__ __forceinline__ void mk_stage(const DevG &D, Sm *sm, long long &mcb, 
     }
 }
 
-__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, QRef &qr)
+// Column singletons.  While the count-1 list is not empty its first column is the pivot column: its one
+// entry costs (1-1)*(r-1) = 0 and no later candidate can be strictly cheaper (markowitz.rs:105); the
+// reference still looks at maxsearch columns (or all that are left), which only shows in nsearch_pivot.
+// So for these -- half of all pivots of an LP basis -- the other candidates are neither walked nor
+// staged: 4 dependent loads (list heads, column, entry, row) instead of 6, and no reduction.
+// Returns false (nothing modified) if the count-1 list is empty or anything is unusual; the caller
+// then takes the ordinary route, which also raises the errors.
+__device__ __forceinline__ bool mk_express(const DevG &D, Sm *sm, int &nsearched)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false;
+    const int h0 = D.cflink[m], j = D.cflink[m + 1];
+    if (h0 != m || j >= m) return false;
+    const int cb = D.cbeg[j], cl = D.clen[j];
+    const double cmx = D.colmax[j];
+    if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false;
+    const int idx = D.cidx[cb];
+    const double val = D.cval[cb];
+    const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+    const double tol = fmax(D.abstol, D.reltol * cmx);
+    const double x = fabs(val);
+    if (x == 0.0 || x < tol) return false;
+    const int left = m - sm->rank - sm->rankdef; // every active column is in a count list, list 0 is empty
+    nsearched = left < K ? left : K;
+    if (lane == 0) {
+        fa->ncand = 1;
+        fa->cJ[0] = j;
+        fa->cNz[0] = 1;
+        fa->cB[0] = cb;
+        fa->cL[0] = 1;
+        fa->cMx[0] = cmx;
+        fa->cOff[0] = 0;
+        fa->cOff[1] = 1;
+        fa->sI[0] = idx;
+        fa->sV[0] = val;
+        fa->sB[0] = rb;
+        fa->sL[0] = rl;
+        fa->sC[0] = rc;
+        if (BLU_QUEUE) fa->qN = 0;
+    }
+    wave_mem_sync();
+    return true;
+}
+
+__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, QRef &qr, int nsearched)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -551,7 +669,7 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
         sm->prb = prb;
         sm->nzc = nzc;
         sm->nzr = nzr;
-        sm->nsearch += ncand;
+        sm->nsearch += nsearched;
         sm->min_colnz = fa->cNz[0];
         sm->flag_small = 0;
         sm->ncancel = 0;
@@ -603,7 +721,7 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
     qref_consume(D, fa, qr); // (its loads were issued before those of the pivot row: no extra wait)
     qref_issue(D, fa, qr);
     for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
-    for (int s = lane; s < HCOL; s += 64) fa->hColK[s] = -1;
+    for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
     long long gc = 0, gr = 0;
 #pragma unroll
     for (int c = 0; c < PRMAX / 64; c++) {
@@ -616,7 +734,7 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
             fa->tB[slot] = tb;
             fa->tL[slot] = tl;
             fa->tC[slot] = tc;
-            hcol_insert(fa, j);
+            hcol_insert(fa, j, slot);
             if (kind == 1 && q != wpos) {
                 const int n = tl + nzc - 1;
                 gc += n + stretch_of(D.stretch, n) + D.pad;
@@ -650,6 +768,15 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
     Fast *fa = &sm->fa;
     if (lane_id() == 0) fa->kind = 0;
     PROF_STAMP(8);
+    int nsr = 0;
+    if (mk_express(D, sm, nsr)) {
+        PROF_STAMP(9);
+        PROF_STAMP(10);
+        QRef q0;
+        q0.kind = 0;
+        mk_pick(D, sm, 0, 0, q0, nsr);
+        return true;
+    }
     int r = q_prepare(D, sm);
     if (r == 2) {
         r = mk_walk(D, sm);
@@ -710,7 +837,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
     PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
     qref_consume(D, fa, qr);
     qref_issue(D, fa, qr);
-    mk_pick(D, sm, mcb, fb, qr);
+    mk_pick(D, sm, mcb, fb, qr, fa->ncand);
     return true;
 }
 
@@ -719,13 +846,12 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // idx_first/val_first: this lane's entry of the first 64-entry chunk, loaded by the caller ahead of
 // time (the caller issues the loads of all its tasks before processing any of them)
-__device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *work, int idx_first, double val_first)
+__device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *work, int idx_first, double val_first, int pr, int cnz1,
+                                         double pivot)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
-    const int pr = sm->pr, cnz1 = sm->nzc - 1;
-    const double pivot = fa->pcV[0];
     const int j = fa->tJ[q], cb = fa->tB[q], cl = fa->tL[q], cap = fa->tC[q];
 
     int nkept = 0, where = -1, first_idx = 0;
@@ -848,12 +974,11 @@ __device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *w
 
 // kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
 // cancelled by fast_col are removed afterwards by fast_fixrow.
-__device__ __forceinline__ void fast_row(const DevG &D, Sm *sm, int p, int j_first)
+__device__ __forceinline__ void fast_row(const DevG &D, Sm *sm, int p, int j_first, int pc, int rnz1)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
-    const int pc = sm->pc, rnz1 = sm->nzr - 1;
     const int i = fa->pcI[p], rb = fa->prB[p], rl = fa->prL[p], cap = fa->prC[p];
 
     int nk = 0;
@@ -997,47 +1122,78 @@ __device__ __forceinline__ void fast_write_l(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_small(const DevG &D, Sm *sm)
+__device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc, int nzc, int nzr)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
     Fast *fa = &sm->fa;
-    const int pr = sm->pr, pc = sm->pc;
-    const int cnz1 = sm->nzc - 1, rnz1 = sm->nzr - 1;
-    DEV_CHECK(D.s, fa->pcV[0] != 0.0);
+    const int cnz1 = nzc - 1, rnz1 = nzr - 1;
+    const double pivot = fa->pcV[0];
+    DEV_CHECK(D.s, pivot != 0.0);
 
     double *work = &sm->swork[w * 64];
-    // tasks 0..rnz1-1 = columns of the pivot row, rnz1.. = rows of the pivot column; wave w takes
-    // t = w, w+nw, ...  Three tasks at a time: all first-chunk loads are issued before any of the
-    // lines is processed, so their latencies overlap instead of adding up.
+    // tasks 0..rnz1-1 = columns of the pivot row, rnz1.. = rows of the pivot column.  Three tasks at a
+    // time: all first-chunk loads are issued before any of the lines is processed, so their latencies
+    // overlap instead of adding up.  A column costs about twice a row, so the second of the three goes
+    // round the waves in reverse: the waves that got the last columns get no second column.
     const int ntask = rnz1 + cnz1;
     PROF_STAMP(4);
-    for (int t0 = w; t0 < ntask; t0 += 3 * nw) {
-        int li[3];
+    for (int base = 0; base < ntask; base += 3 * nw) {
+        int li[3], tt[3];
         double lv[3];
+        tt[0] = base + w;
+        tt[1] = base + 2 * nw - 1 - w;
+        tt[2] = base + 2 * nw + w;
+        // (begin, len) of the three lines first, unconditionally (slot 0 stands in for "no task"): the LDS
+        // reads are independent and return together
+        int lb[3], ll[3];
+        bool isc[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const int t = t0 + u * nw;
+            const int t = tt[u];
+            isc[u] = t < rnz1;
+            const bool isr = !isc[u] && t < ntask;
+            const int q = isc[u] ? t + 1 : 0, p = isr ? t - rnz1 + 1 : 0;
+            const int cb_ = fa->tB[q], cl_ = fa->tL[q], rb_ = fa->prB[p], rl_ = fa->prL[p];
+            lb[u] = isc[u] ? cb_ : rb_;
+            ll[u] = isc[u] ? cl_ : (isr ? rl_ : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
             li[u] = -1;
             lv[u] = 0.0;
-            if (t < rnz1) {
-                const int q = t + 1;
-                if (lane < fa->tL[q]) {
-                    li[u] = D.cidx[fa->tB[q] + lane];
-                    lv[u] = D.cval[fa->tB[q] + lane];
+            if (lane < ll[u]) {
+                if (isc[u]) {
+                    li[u] = D.cidx[lb[u] + lane];
+                    lv[u] = D.cval[lb[u] + lane];
+                } else {
+                    li[u] = D.ridx[lb[u] + lane];
                 }
-            } else if (t < ntask) {
-                const int p = t - rnz1 + 1;
-                if (lane < fa->prL[p]) li[u] = D.ridx[fa->prB[p] + lane];
             }
         }
+#ifdef BLU_PROFILE
+        if (w == 1 && base == 0) {
+            PROF_STAMP_L0(33);
+            PROF_WAIT();
+            PROF_STAMP_L0(34);
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const int t = t0 + u * nw;
-            if (t < rnz1) fast_col(D, sm, t + 1, work, li[u], lv[u]);
-            else if (t < ntask) fast_row(D, sm, t - rnz1 + 1, li[u]);
+            const int t = tt[u];
+            if (t < rnz1) fast_col(D, sm, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
+            else if (t < ntask) fast_row(D, sm, t - rnz1 + 1, li[u], pc, rnz1);
+#ifdef BLU_PROFILE
+            if (w == 1 && base == 0) PROF_STAMP_L0(35 + u);
+#endif
         }
     }
+#ifdef BLU_PROFILE
+    if (w == 1) {
+        PROF_WAIT();
+        PROF_STAMP_L0(38);
+    }
+#endif
     PROF_STAMP(5);
     __syncthreads();
     PROF_STAMP(3);
@@ -1059,21 +1215,21 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm)
         }
         PROF_STAMP(6);
     }
-    if (w == 1 % nw) fast_write_l(D, sm);
+    if (w == 1 % nw) {
+        fast_write_l(D, sm);
+        PROF_STAMP_L0(24);
+    }
     if (w == 2 % nw) {
-#ifdef BLU_PROFILE
-        if (lane == 0) sm->pstamp[7] = (long long)__builtin_amdgcn_s_memtime();
-#endif
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa}, m + 2, pc, fa->ls[0]);
+        PROF_STAMP_L0(25);
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->ls[0], fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
-#ifdef BLU_PROFILE
-        if (lane == 0) sm->pstamp[8] = (long long)__builtin_amdgcn_s_memtime();
-#endif
+        PROF_WAIT();
+        PROF_STAMP_L0(29);
     }
     if (D.search_rows && w == 3 % nw) {
         if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1]);
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1], fa->kg[1]);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
     __syncthreads();
@@ -1082,13 +1238,12 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm)
+__device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc, int rl, int wq)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
-    const int pr = sm->pr, pc = sm->pc, rl = sm->nzr, wq = fa->where;
     DEV_CHECK(S, fa->pcV[0] != 0.0 && fa->pcI[0] == pr);
 
     for (int q = w; q < rl; q += nw) {
@@ -1145,7 +1300,7 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm)
     if (w == 1 % nw) {
         if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
         // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa}, m + 2, pc, fa->ls[0]);
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->ls[0], fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
     }
     __syncthreads();

@@ -5,7 +5,10 @@
 #define STGMAX 192  // staged Markowitz candidate entries
 #define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
 #define HROW 256    // hash slots, rows of the pivot column (<= 64 keys)
-#define HCOL 1024   // hash slots, columns of the pivot row (<= 256 keys)
+#define HCOL 512    // hash slots, columns of the pivot row (<= 256 keys)
+#define KGMAX 256    // batched list moves: keys (new counts) below this meet in an LDS table
+#define HROW_BITS 8
+#define HCOL_BITS 9
 #define QMAX 8      // candidate queue: leading columns of the count lists kept across pivots
 // The queue is compiled out by default: on banded LP bases most queued columns sit in the very next
 // pivot row (24 % of the searches of the 100k benchmark basis were served from it, the top-up loads
@@ -38,7 +41,8 @@ struct Fast {
     int sI[STGMAX], sB[STGMAX], sL[STGMAX], sC[STGMAX];
     double sV[STGMAX];
     unsigned long long hRow[HROW]; // (row index << 32) | position, ~0 = empty: one LDS read per probe
-    int hColK[HCOL];
+    unsigned long long hCol[HCOL]; // (column index << 32) | slot in tJ, ~0 = empty
     int ls[2][320]; // scratch of the batched list moves (0: column lists, 1: row lists)
+    unsigned long long kg[2][KGMAX]; // key -> lanes with that key, all zero between list moves
 };
 
