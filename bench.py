@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=256, help="bases in flight for the secondary throughput measurement (0 = skip)")
-    ap.add_argument("--batch-block", type=int, default=512, help="workgroup size of the pivot kernel in batch mode")
+    ap.add_argument("--batch", type=int, default=1024, help="bases in flight for the secondary throughput measurement (0 = skip)")
+    ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the pivot kernel in batch mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

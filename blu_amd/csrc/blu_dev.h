@@ -165,9 +165,13 @@ __device__ __forceinline__ int num_waves() { return blockDim.x >> 6; }
 
 __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// Orders this wave's earlier global/LDS accesses before its later ones (s_waitcnt vmcnt(0) lgkmcnt(0))
-// and is a compiler barrier.  Needed where one lane's store feeds another lane's later load.
-__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// Orders this wave's earlier global/LDS accesses before its later ones, for the lanes of THIS wave:
+// needed where one lane's store feeds another lane's later load.  A wave's memory instructions are
+// performed in issue order (LDS unit and vector L1 are in-order per wave), so at wavefront scope the
+// fence emits no instruction -- it only keeps the compiler from moving accesses across it.  (A
+// workgroup-scope fence here would drain vmcnt/lgkmcnt: one store round trip per call.)
+// Communication BETWEEN waves goes through __syncthreads().
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 // Wave-wide all-reductions through rocPRIM's DPP implementation (row_shr / row_bcast data-parallel
 // primitives: ~6 VALU ops per 32-bit word) instead of __shfl_xor butterflies, which compile to

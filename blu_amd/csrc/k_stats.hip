@@ -15,51 +15,183 @@
 // +-1 right-hand-side choices (`temp >= 0`, `d <= 0`) are made on identically defined quantities.
 #include "blu_dev.h"
 
-// ordered dot: sum_{p in [b,e)} x[idx[p]] * val[p], accumulated sequentially in storage order.
-// Lanes fetch, lane 0 accumulates from LDS (`buf`: 64 doubles of this wave).  All lanes return the sum.
-__device__ __forceinline__ double wave_ordered_dot(const long long *idx, const double *val, long long b, long long e,
-                                                   gdouble_p x, double *buf)
-{
-    const int lane = lane_id();
-    double acc = 0.0;
-    for (long long c = b; c < e; c += 64) {
-        const long long p = c + lane;
-        double prod = 0.0;
-        if (p < e) prod = __dmul_rn(x[(int)idx[p]], val[p]);
-        buf[lane] = prod;
-        wave_mem_sync();
-        if (lane == 0) {
-            const int n = (int)((e - c) < 64 ? (e - c) : 64);
-            for (int t = 0; t < n; t++) acc = __dadd_rn(acc, buf[t]);
-        }
-        wave_mem_sync();
+typedef GPTR(const long long) gcll_p;
+typedef GPTR(const double) gcdouble_p;
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined triangular sweeps.  A sweep is a chain of m dependent steps: step k reads entries of the
+// work vector that step k-1 may just have written.  What does NOT depend on the previous step -- the
+// column pointers, the column's (index, value) entries, its diagonal / pivot row -- is fetched one and
+// two steps ahead, so that a step costs ONE memory round trip (the gather of the work vector) instead
+// of four.  Lanes hold one entry each of the first 64 of a column; longer columns (rare) take the slow
+// tail loops.  One lane's store to the work vector is seen by the other lanes' later loads without a
+// drain: a wave's memory operations are performed in order (wave_mem_sync = wavefront-scope fence).
+// ------------------------------------------------------------------------------------------------
+struct ColPtr {
+    long long b, e; // entries [b, e)
+    double diag;    // U: pivot (last entry of the column); unused for L
+    int aux;        // stage L: prow[k]
+};
+struct ColEnt {
+    int idx;
+    double val;
+};
+// U columns of the canonical factors: off-diagonals [colptr[k], colptr[k+1]-1), pivot last
+struct UCols {
+    gcll_p colptr, rowidx;
+    gcdouble_p value;
+    int m;
+    __device__ __forceinline__ ColPtr ptr(int k) const
+    {
+        ColPtr P;
+        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
+        P.b = colptr[k];
+        P.e = colptr[k + 1] - 1;
+        P.diag = 0.0;
+        P.aux = 0;
+        return P;
     }
-    return __shfl(acc, 0);
+    __device__ __forceinline__ void diag(ColPtr &P) const { P.diag = value[P.e]; }
+    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
+    {
+        ColEnt E;
+        E.idx = 0;
+        E.val = 0.0;
+        const long long p = P.b + off + lane_id();
+        if (p < P.e) {
+            E.idx = (int)rowidx[p];
+            E.val = value[p];
+        }
+        return E;
+    }
+};
+// sorted L columns of the canonical factors without the unit diagonal: (colptr[k], colptr[k+1])
+struct LCols {
+    gcll_p colptr, rowidx;
+    gcdouble_p value;
+    int m;
+    __device__ __forceinline__ ColPtr ptr(int k) const
+    {
+        ColPtr P;
+        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
+        P.b = colptr[k] + 1;
+        P.e = colptr[k + 1];
+        P.diag = 1.0;
+        P.aux = 0;
+        return P;
+    }
+    __device__ __forceinline__ void diag(ColPtr &) const {}
+    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
+    {
+        ColEnt E;
+        E.idx = 0;
+        E.val = 0.0;
+        const long long p = P.b + off + lane_id();
+        if (p < P.e) {
+            E.idx = (int)rowidx[p];
+            E.val = value[p];
+        }
+        return E;
+    }
+};
+// stage-ordered L columns as the pivot loop wrote them (row indices of B): the reference's own storage
+// and summation order (l_begin_p, pivot.rs:404-416); `map` (or null) takes a row index to its position
+struct LStage {
+    gcint_p lbeg, lidx, prow, map;
+    gcdouble_p lval;
+    int m;
+    __device__ __forceinline__ ColPtr ptr(int k) const
+    {
+        ColPtr P;
+        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
+        P.b = lbeg[k];
+        P.e = lbeg[k + 1];
+        P.diag = 1.0;
+        P.aux = prow[k];
+        return P;
+    }
+    __device__ __forceinline__ void diag(ColPtr &) const {}
+    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
+    {
+        ColEnt E;
+        E.idx = 0;
+        E.val = 0.0;
+        const long long p = P.b + off + lane_id();
+        if (p < P.e) {
+            const int i = lidx[p];
+            E.idx = map ? map[i] : i;
+            E.val = lval[p];
+        }
+        return E;
+    }
+};
+
+// sum of prod over lanes 0..n-1 in lane order, every lane gets it (the reference's sequential loop)
+__device__ __forceinline__ double wave_ordered_sum(double prod, int n, double acc)
+{
+    const unsigned lo = (unsigned)__double_as_longlong(prod), hi = (unsigned)(__double_as_longlong(prod) >> 32);
+    for (int t = 0; t < n; t++) {
+        const unsigned a = __builtin_amdgcn_readlane(lo, t), b = __builtin_amdgcn_readlane(hi, t);
+        acc = __dadd_rn(acc, __longlong_as_double((long long)(((unsigned long long)b << 32) | a)));
+    }
+    return acc;
 }
 
-// same over a stage-ordered L column (row indices of B, optionally mapped to pivot positions by `map`):
-// this IS the reference's storage order for L columns (l_begin_p, pivot.rs:404-416)
-__device__ __forceinline__ double wave_ordered_dot_stage(gcint_p idx, gdouble_p val, int b, int e, gdouble_p x, gcint_p map,
-                                                         double *buf)
+// ordered dot of column P with the work vector x (first chunk E already in registers)
+template <class Cols>
+__device__ __forceinline__ double col_dot(const Cols &C, const ColPtr &P, const ColEnt &E, gdouble_p x)
 {
+    const long long len = P.e - P.b;
+    if (len <= 0) return 0.0;
     const int lane = lane_id();
-    double acc = 0.0;
-    for (int c = b; c < e; c += 64) {
-        const int p = c + lane;
-        double prod = 0.0;
-        if (p < e) {
-            const int i = idx[p];
-            prod = __dmul_rn(x[map ? map[i] : i], val[p]);
-        }
-        buf[lane] = prod;
-        wave_mem_sync();
-        if (lane == 0) {
-            const int n = (e - c) < 64 ? (e - c) : 64;
-            for (int t = 0; t < n; t++) acc = __dadd_rn(acc, buf[t]);
-        }
-        wave_mem_sync();
+    const int n0 = len < 64 ? (int)len : 64;
+    double acc = wave_ordered_sum(lane < n0 ? __dmul_rn(x[E.idx], E.val) : 0.0, n0, 0.0);
+    for (long long off = 64; off < len; off += 64) {
+        const ColEnt E2 = C.ent(P, off);
+        const int n = (len - off) < 64 ? (int)(len - off) : 64;
+        acc = wave_ordered_sum(lane < n ? __dmul_rn(x[E2.idx], E2.val) : 0.0, n, acc);
     }
-    return __shfl(acc, 0);
+    return acc;
+}
+// x[idx] = x[idx] -/+ t * val over column P (sub: minus)
+template <bool SUB, class Cols>
+__device__ __forceinline__ void col_scatter(const Cols &C, const ColPtr &P, const ColEnt &E, gdouble_p x, double t)
+{
+    const long long len = P.e - P.b;
+    const int lane = lane_id();
+    if (lane < len) {
+        const double pr = __dmul_rn(t, E.val);
+        x[E.idx] = SUB ? __dsub_rn(x[E.idx], pr) : __dadd_rn(x[E.idx], pr);
+    }
+    for (long long off = 64; off < len; off += 64) {
+        const ColEnt E2 = C.ent(P, off);
+        if (off + lane < len) {
+            const double pr = __dmul_rn(t, E2.val);
+            x[E2.idx] = SUB ? __dsub_rn(x[E2.idx], pr) : __dadd_rn(x[E2.idx], pr);
+        }
+    }
+}
+
+// for k = k0, k0+dir, .. (n steps): body(k, P_k, E_k) with the pointers of step k+2 and the entries of
+// step k+1 in flight
+template <class Cols, class Body>
+__device__ __forceinline__ void sweep(const Cols &C, int k0, int dir, int n, Body body)
+{
+    if (n <= 0) return;
+    ColPtr P1 = C.ptr(k0);
+    C.diag(P1);
+    ColEnt E1 = C.ent(P1, 0);
+    ColPtr P2 = C.ptr(k0 + dir);
+    for (int s = 0, k = k0; s < n; s++, k += dir) {
+        C.diag(P2);
+        const ColEnt E2 = C.ent(P2, 0);
+        const ColPtr P3 = C.ptr(k + 2 * dir);
+        body(k, P1, E1);
+        wave_mem_sync();
+        P1 = P2;
+        E1 = E2;
+        P2 = P3;
+    }
 }
 
 __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
@@ -67,7 +199,6 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
     const DevG D(Ds[blockIdx.x]);
     const FinishOut &O = Os[blockIdx.x];
     Scalars *S = D.s;
-    __shared__ double bufs[4][64];
     __shared__ double red[4][40];
     __shared__ double chain_out[16];
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), lane = lane_id(), nw = num_waves();
@@ -79,123 +210,99 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
               rf = D.gwork + 3 * (size_t)(m + 1), lb = D.gwork + 4 * (size_t)(m + 1), rb = D.gwork + 5 * (size_t)(m + 1);
     gdouble_p rs = D.gwork + 6 * (size_t)(m + 1); // row sums of |B|
 
-    const int chain = nw >= 4 ? w : -1;
+    const UCols CU{(gcll_p)O.u_colptr, (gcll_p)O.u_rowidx, (gcdouble_p)O.u_value, m};
+    const LCols CL{(gcll_p)O.l_colptr, (gcll_p)O.l_rowidx, (gcdouble_p)O.l_value, m};
+    const LStage CS{D.lbeg, D.lidx, D.prow, nullptr, D.lval, m};
+    const LStage CSmap{D.lbeg, D.lidx, D.prow, D.pinv, D.lval, m};
     for (int cc = 0; cc < 4; cc++) {
         // with fewer than 4 waves the chains run one after the other on wave 0
         const bool mine = nw >= 4 ? (w == cc) : (w == 0);
         if (!mine) continue;
-        double *buf = bufs[nw >= 4 ? cc : 0];
         if (cc == 0) {
             // ---- condest(L): L' x = b with b = +-1 chosen on the fly, k descending (condest.rs:101-116, upper = 0)
-            // This chain works in ROW-INDEX coordinates on the stage-ordered L columns, the reference's own
-            // storage and summation order (wl[i], i = row of B).
+            // This chain works in ROW-INDEX coordinates on the stage-ordered L columns (wl[i], i = row of B).
             double x1 = 0.0, xinf = 0.0;
-            for (int k = m - 1; k >= 0; k--) {
-                const int b = D.lbeg[k], e = D.lbeg[k + 1];
+            sweep(CS, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
                 double temp = 0.0;
-                if (e > b) temp = -wave_ordered_dot_stage(D.lidx, D.lval, b, e, wl, nullptr, buf); // temp -= work[i]*x
+                if (P.e > P.b) temp = -col_dot(CS, P, E, wl); // temp -= work[i]*x
                 temp += temp >= 0.0 ? 1.0 : -1.0;
-                if (lane == 0) wl[D.prow[k]] = temp;
+                if (lane == 0) wl[P.aux] = temp;
                 x1 += fabs(temp);
                 xinf = fmax(xinf, fabs(temp));
-                wave_mem_sync();
-            }
+            });
             // L y = x, k ascending, scatter (condest.rs:135-154)
             double y1 = 0.0;
-            for (int k = 0; k < m; k++) {
-                const int b = D.lbeg[k], e = D.lbeg[k + 1];
-                const double temp = wl[D.prow[k]];
-                for (int p = b + lane; p < e; p += 64) {
-                    const int r = D.lidx[p];
-                    wl[r] = __dsub_rn(wl[r], __dmul_rn(temp, D.lval[p]));
-                }
+            sweep(CS, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+                const double temp = wl[P.aux];
+                col_scatter<true>(CS, P, E, wl, temp);
                 y1 += fabs(temp);
-                if (e > b) wave_mem_sync();
-            }
-            if (lane == 0) {
-                chain_out[0] = fmax(y1 / x1, xinf); // normest_l_inv
-            }
+            });
+            if (lane == 0) chain_out[0] = fmax(y1 / x1, xinf); // normest_l_inv
         } else if (cc == 1) {
             // ---- condest(U): U' x = b, k ascending, then U y = x, k descending (upper = 1, pivots = diagonal)
             double x1 = 0.0, xinf = 0.0;
-            for (int k = 0; k < m; k++) {
-                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+            sweep(CU, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
                 double temp = 0.0;
-                if (e > b) temp = -wave_ordered_dot(O.u_rowidx, O.u_value, b, e, wu, buf);
+                if (P.e > P.b) temp = -col_dot(CU, P, E, wu);
                 temp += temp >= 0.0 ? 1.0 : -1.0;
-                temp /= O.u_value[e];
+                temp /= P.diag;
                 if (lane == 0) wu[k] = temp;
                 x1 += fabs(temp);
                 xinf = fmax(xinf, fabs(temp));
-                wave_mem_sync();
-            }
+            });
             double y1 = 0.0;
-            for (int k = m - 1; k >= 0; k--) {
-                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
-                const double temp = wu[k] / O.u_value[e];
+            sweep(CU, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+                const double temp = wu[k] / P.diag;
+                wave_mem_sync(); // every lane has read wu[k] before lane 0 rewrites it
                 if (lane == 0) wu[k] = temp;
-                for (long long p = b + lane; p < e; p += 64) {
-                    const int r = (int)O.u_rowidx[p];
-                    wu[r] = __dsub_rn(wu[r], __dmul_rn(temp, O.u_value[p]));
-                }
+                col_scatter<true>(CU, P, E, wu, temp);
                 y1 += fabs(temp);
-                wave_mem_sync();
-            }
+            });
             if (lane == 0) chain_out[1] = fmax(y1 / x1, xinf); // normest_u_inv
         } else if (cc == 2) {
             // ---- residual test, forward system (residual_test.rs:43-66): lhs = L\rhs with rhs = +-1 on the fly.
             // The reference takes row dots of L; the column scatter below adds the same products to each
             // accumulator in the same (ascending stage) order.  lf[k] first accumulates d, then holds lhs.
-            for (int k = 0; k < m; k++) {
+            sweep(CL, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
                 const double d = lf[k];
                 const double r = d <= 0.0 ? 1.0 : -1.0;
                 const double x = r - d;
+                wave_mem_sync();
                 if (lane == 0) {
                     rf[k] = r;
                     lf[k] = x;
                 }
-                const long long b = O.l_colptr[k] + 1, e = O.l_colptr[k + 1];
-                for (long long p = b + lane; p < e; p += 64) {
-                    const int rr = (int)O.l_rowidx[p];
-                    lf[rr] = __dadd_rn(lf[rr], __dmul_rn(x, O.l_value[p]));
-                }
-                wave_mem_sync();
-            }
+                col_scatter<false>(CL, P, E, lf, x);
+            });
             // overwrite lhs by U\lhs, k descending (residual_test.rs:57-66)
-            for (int k = m - 1; k >= 0; k--) {
-                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
-                const double d = lf[k] / O.u_value[e];
-                if (lane == 0) lf[k] = d;
-                for (long long p = b + lane; p < e; p += 64) {
-                    const int r = (int)O.u_rowidx[p];
-                    lf[r] = __dsub_rn(lf[r], __dmul_rn(d, O.u_value[p]));
-                }
+            sweep(CU, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+                const double d = lf[k] / P.diag;
                 wave_mem_sync();
-            }
+                if (lane == 0) lf[k] = d;
+                col_scatter<true>(CU, P, E, lf, d);
+            });
         } else {
             // ---- residual test, backward system (residual_test.rs:85-108): lhs = U'\rhs, then L'\lhs
-            for (int k = 0; k < m; k++) {
-                const long long b = O.u_colptr[k], e = O.u_colptr[k + 1] - 1;
+            sweep(CU, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
                 double d = 0.0;
-                if (e > b) d = wave_ordered_dot(O.u_rowidx, O.u_value, b, e, lb, buf);
+                if (P.e > P.b) d = col_dot(CU, P, E, lb);
                 const double r = d <= 0.0 ? 1.0 : -1.0;
                 if (lane == 0) {
                     rb[k] = r;
-                    lb[k] = (r - d) / O.u_value[e];
+                    lb[k] = (r - d) / P.diag;
                 }
-                wave_mem_sync();
-            }
-            for (int k = m - 1; k >= 0; k--) { // dots with the stage-ordered L columns (rows mapped to positions)
-                const int b = D.lbeg[k], e = D.lbeg[k + 1];
-                if (e > b) {
-                    const double d = wave_ordered_dot_stage(D.lidx, D.lval, b, e, lb, D.pinv, buf);
-                    if (lane == 0) lb[k] = lb[k] - d;
+            });
+            // dots with the stage-ordered L columns (rows mapped to positions), k descending
+            sweep(CSmap, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+                if (P.e > P.b) {
+                    const double d = col_dot(CSmap, P, E, lb);
+                    const double v = lb[k] - d;
                     wave_mem_sync();
+                    if (lane == 0) lb[k] = v;
                 }
-            }
+            });
         }
     }
-    (void)chain;
     __syncthreads();
 
     // ---- norms of L and U (condest.rs:27-44), 1-norm = max column sum
