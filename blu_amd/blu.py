@@ -73,6 +73,7 @@ def lib():
         L.blu_hip_factorize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.blu_hip_get_factors.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.blu_hip_solve_dense.argtypes = [C.c_void_p, _f64p, _f64p, C.c_char]
+        L.blu_hip_solve_sparse.argtypes = [C.c_void_p, C.c_int64, _u64p, _f64p, C.c_void_p, C.c_void_p, _f64p, C.c_char]
         L.blu_hip_version.restype = C.c_char_p
         L.blu_hip_last_error.restype = C.c_char_p
         L.blu_hip_last_error.argtypes = [C.c_void_p]
@@ -149,6 +150,8 @@ class BLU:
 
     def __init__(self, m, b_nz, device=0):
         self.m = int(m)
+        self.lhs = self.ilhs = None  # BLU.lhs / BLU.ilhs / BLU.nzlhs (blu.rs:12-17): solve_sparse results
+        self.nzlhs = 0
         self._h = lib().blu_hip_new(int(m), int(b_nz), int(device))
         if not self._h:
             raise BluError(K.ERROR_DEVICE, "blu_hip_new failed (no gfx950 device, bad argument or out of memory)")
@@ -223,6 +226,33 @@ class BLU:
         if st != K.OK:
             raise BluError(st, self.last_error())
         return lhs
+
+    # --- BLU::solve_sparse (blu.rs:207) ------------------------------------------------------------
+    def solve_sparse(self, irhs, xrhs, trans="N"):
+        """Sparse right-hand side irhs/xrhs -> solution.  As in the reference the result stays in the
+        object: self.lhs (dense, m), self.ilhs[0..self.nzlhs) the pattern in the reference's order.
+        The previous solution is cleared first (lu_clear_lhs, blu.rs:380-395).  Returns the status."""
+        m = self.m
+        if self.lhs is None:
+            self.lhs = np.zeros(m)
+            self.ilhs = np.zeros(max(1, m), np.int64)
+            self.nzlhs = 0
+        if self.nzlhs:
+            if self.nzlhs <= int(self.get_param(K.PARAM_SPARSE_THRES) * m):
+                self.lhs[self.ilhs[:self.nzlhs]] = 0.0
+            else:
+                self.lhs[:] = 0.0
+            self.nzlhs = 0
+        ir = np.ascontiguousarray(irhs, dtype=np.uint64)
+        xr = np.ascontiguousarray(xrhs, dtype=np.float64)
+        nz = C.c_int64(0)
+        st = lib().blu_hip_solve_sparse(self._h, len(ir), _p(ir, _u64p), _p(xr, _f64p), C.byref(nz),
+                                        self.ilhs.ctypes.data, _p(self.lhs, _f64p), trans.encode()[0:1])
+        if st == K.OK:
+            self.nzlhs = int(nz.value)
+        elif st in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):
+            raise BluError(st, self.last_error())
+        return st
 
     # --- test hooks (step-wise comparison with the oracle) -------------------------------------------
     def dbg_set_stop(self, n):

@@ -20,6 +20,7 @@
 #include "k_pivot.hip"
 #include "k_prep.hip"
 #include "k_solve.hip"
+#include "k_solve_sparse.hip"
 #include "k_stats.hip"
 
 #define BLU_STOPPED_STATUS 100 /* debug stepping only */
@@ -50,6 +51,17 @@ struct blu_hip {
     // solve workspace
     double *d_rhs, *d_lhs;
     int *lvl_l, *lvl_u;
+    // solve_sparse workspace (allocated at the first call)
+    SparseWs sw;
+    bool sw_ready;
+    int64_t sw_ltcap;       // entries of the row-wise L buffers
+    int64_t lt_for_nfact;   // nfactorize the row-wise L was built for (-1: none)
+    int marker;             // lu.marker (src/lu/lu.rs:128)
+    int *d_irhs;
+    double *d_xrhs;
+    int64_t rhs_cap;
+    int64_t sp_l_flops, sp_u_flops; // lu.l_flops / lu.u_flops
+    int sp_branch;                  // 1 sparse, 2 sequential: branch of the last solve_sparse (diagnostic)
     // timing
     hipStream_t stream;
     hipEvent_t ev[4];
@@ -108,6 +120,10 @@ static void free_all(blu_hip *h)
     dfree(D.lidx); dfree(D.uidx); dfree(D.lval); dfree(D.uval);
     dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value);
     dfree(h->ob_begin); dfree(h->ob_end); dfree(h->ob_i); dfree(h->ob_x);
+    SparseWs &W = h->sw;
+    dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
+    dfree(W.xval); dfree(W.out); dfree(W.lt_ptr); dfree(W.lt_idx); dfree(W.lt_val); dfree(W.lt_cur);
+    dfree(h->d_irhs); dfree(h->d_xrhs);
     // everything else lives in the slab
     dfree(h->slab);
 }
@@ -170,6 +186,16 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->realloc_factor = 1.5;
     h->nupdate = -1;
     h->nfactorize = 0;
+    memset(&h->sw, 0, sizeof(SparseWs));
+    h->sw_ready = false;
+    h->sw_ltcap = 0;
+    h->lt_for_nfact = -1;
+    h->marker = 0;
+    h->d_irhs = nullptr;
+    h->d_xrhs = nullptr;
+    h->rhs_cap = 0;
+    h->sp_l_flops = h->sp_u_flops = 0;
+    h->sp_branch = 0;
     h->stop_at = -1;
     h->block_threads = 1024;
     h->no_fast = 0;
@@ -319,6 +345,9 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_L_MEM: return (double)h->D.lcap;
     case BLU_STAT_U_MEM: return (double)h->D.ucap;
     case BLU_STAT_W_MEM: return (double)h->D.carena_cap + (double)h->D.rarena_cap;
+    case BLU_STAT_L_FLOPS: return (double)h->sp_l_flops;
+    case BLU_STAT_U_FLOPS: return (double)h->sp_u_flops;
+    case 43: return (double)h->sp_branch; // branch of the last solve_sparse: 1 sparse, 2 sequential
     case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;
     case BLU_STAT_DEV_TIME_TOTAL: return h->t_total;
     case BLU_STAT_DEV_RELAUNCHES: return (double)h->relaunches;
@@ -478,6 +507,89 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO, h->d_rhs, h->d_lhs, tr);
     if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_dense")) return BLU_ERROR_DEVICE;
     if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
+    return BLU_OK;
+}
+
+// solve_sparse -- src/solve_sparse.rs:36-68, lu/solve_sparse.rs:11-360 (fresh factorization: nforrest == 0)
+extern "C" int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *irhs, const double *xrhs, int64_t *p_nzlhs,
+                                    int64_t *ilhs, double *lhs, char trans)
+{
+    if (!h) return BLU_ERROR_ARGUMENT_MISSING;
+    if (h->nupdate < 0) return BLU_ERROR_INVALID_CALL; // solve_sparse.rs:46-47
+    if (!p_nzlhs || !ilhs || !lhs || (nzrhs > 0 && (!irhs || !xrhs))) return BLU_ERROR_ARGUMENT_MISSING;
+    // check RHS indices (solve_sparse.rs:49-59)
+    bool ok = nzrhs >= 0 && nzrhs <= h->m;
+    for (int64_t n = 0; ok && n < nzrhs; n++) ok = irhs[n] < (uint64_t)h->m;
+    if (!ok) return BLU_ERROR_INVALID_ARGUMENT;
+    *p_nzlhs = 0;
+    if (h->m == 0) return BLU_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
+    const size_t M = (size_t)h->m;
+    SparseWs &W = h->sw;
+    if (!h->sw_ready) {
+        bool a = dalloc(h, &W.marked, M) && dalloc(h, &W.psym, M) && dalloc(h, &W.pat, M) && dalloc(h, &W.pstack, M) &&
+                 dalloc(h, &W.work, M) && dalloc(h, &W.xlhs, M) && dalloc(h, &W.ilhs, M) && dalloc(h, &W.xval, M) &&
+                 dalloc(h, &W.out, 4) && dalloc(h, &W.lt_ptr, M + 1) && dalloc(h, &W.lt_cur, M);
+        a = a && hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset") &&
+            hip_ok(h, hipMemset(W.work, 0, M * sizeof(double)), "hipMemset") &&
+            hip_ok(h, hipMemset(W.xlhs, 0, M * sizeof(double)), "hipMemset");
+        if (!a) return BLU_ERROR_OUT_OF_MEMORY;
+        h->sw_ready = true;
+        h->marker = 0;
+    }
+    if (h->marker > 0x7fffffff - 8) { // lu.rs:301-305: reset the marks before the marker overflows
+        if (!hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset")) return BLU_ERROR_DEVICE;
+        h->marker = 0;
+    }
+    const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
+    if (tr && h->lt_for_nfact != h->nfactorize) { // row-wise L of THIS factorization
+        const int64_t lnz = std::max<int64_t>((int64_t)h->hs.lused, 1);
+        if (lnz > h->sw_ltcap) {
+            dfree(W.lt_idx);
+            dfree(W.lt_val);
+            if (!dalloc(h, &W.lt_idx, (size_t)lnz) || !dalloc(h, &W.lt_val, (size_t)lnz)) return BLU_ERROR_OUT_OF_MEMORY;
+            h->sw_ltcap = lnz;
+        }
+        hipLaunchKernelGGL(k_build_lt, dim3(1), dim3(1024), 0, h->stream, h->dD, W);
+        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_build_lt")) return BLU_ERROR_DEVICE;
+        h->lt_for_nfact = h->nfactorize;
+    }
+    if (nzrhs > h->rhs_cap) {
+        dfree(h->d_irhs);
+        dfree(h->d_xrhs);
+        if (!dalloc(h, &h->d_irhs, (size_t)nzrhs) || !dalloc(h, &h->d_xrhs, (size_t)nzrhs)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->rhs_cap = nzrhs;
+    }
+    if (nzrhs > 0) {
+        std::vector<int> ir((size_t)nzrhs);
+        for (int64_t n = 0; n < nzrhs; n++) ir[(size_t)n] = (int)irhs[n];
+        if (!hip_ok(h, hipMemcpy(h->d_irhs, ir.data(), (size_t)nzrhs * sizeof(int), hipMemcpyHostToDevice), "h2d irhs") ||
+            !hip_ok(h, hipMemcpy(h->d_xrhs, xrhs, (size_t)nzrhs * sizeof(double), hipMemcpyHostToDevice), "h2d xrhs"))
+            return BLU_ERROR_DEVICE;
+    }
+    const int nz_sparse = (int)(h->sparse_thres * (double)h->m); // lu/solve_sparse.rs:24
+    hipLaunchKernelGGL(k_solve_sparse, dim3(1), dim3(64), 0, h->stream, h->dD, h->dO, W, (int)nzrhs, h->d_irhs, h->d_xrhs, tr,
+                       h->marker, nz_sparse);
+    if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_sparse")) return BLU_ERROR_DEVICE;
+    h->marker += 3;
+    long long out[4];
+    if (!hip_ok(h, hipMemcpy(out, W.out, sizeof out, hipMemcpyDeviceToHost), "d2h out")) return BLU_ERROR_DEVICE;
+    const size_t nz = (size_t)out[0];
+    h->sp_l_flops += out[1];
+    h->sp_u_flops += out[2];
+    h->sp_branch = (int)out[3];
+    if (nz > 0) {
+        std::vector<int> il(nz);
+        std::vector<double> xv(nz);
+        if (!hip_ok(h, hipMemcpy(il.data(), W.ilhs, nz * sizeof(int), hipMemcpyDeviceToHost), "d2h ilhs") ||
+            !hip_ok(h, hipMemcpy(xv.data(), W.xval, nz * sizeof(double), hipMemcpyDeviceToHost), "d2h xval"))
+            return BLU_ERROR_DEVICE;
+        for (size_t n = 0; n < nz; n++) { // scatter into the caller's (all-zero) lhs
+            ilhs[n] = il[n];
+            lhs[il[n]] = xv[n];
+        }
+    }
+    *p_nzlhs = (int64_t)nz;
     return BLU_OK;
 }
 

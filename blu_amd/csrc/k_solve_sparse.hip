@@ -1,0 +1,391 @@
+// k_solve_sparse.hip -- solve_sparse for a fresh factorization (nforrest = 0): the hypersparse
+// Gilbert-Peierls solve of src/lu/solve_sparse.rs:11-360 with src/lu/solve_symbolic.rs:19-40,
+// src/lu/dfs.rs:25-145 and src/lu/solve_triangular.rs:27-136, one wave per matrix.
+//
+// The reference's result is more than the solution vector: the pattern ilhs[0..nzlhs) comes out in the
+// order the depth-first searches leave it (reverse post-order over each line's entries in STORAGE
+// order), and which branch runs (symbolic + sparse substitution, or the sequential sweep) depends on
+// nnz of the intermediate vector against sparse_thres*m.  Both are reproduced: the four graphs below
+// present the factors with the entry order build_factors gives them (build_factors.rs:229-384):
+//   GL   L column of row i   = stage column pinv[i], row indices, production order       (forward, 1st)
+//   GU   U column under row i = canonical column pinv[i], rows ascending in pivot order   (forward, 2nd)
+//   GW   U row under column j = stage row qinv[j], production order; entries in columns
+//        without a pivot (rank-deficient factorization) are absent                        (transposed, 1st)
+//   GLt  L row i, ascending in the pivot order of its columns: built by k_build_lt        (transposed, 2nd)
+// The depth-first search is inherently serial: lane 0 runs it.  The numerical substitution visits the
+// columns in that topological order; inside one column the 64 lanes update distinct entries, so every
+// entry sees its updates in the reference's order and the values are bit-identical.
+#include "blu_dev.h"
+
+struct SparseWs {
+    int *marked;     // m, 0 <= marked[i] <= marker (src/lu/lu.rs:164)
+    int *psym;       // m: DFS stack from the front, topological order from the back (pattern_symb)
+    int *pat;        // m: pattern of the intermediate vector
+    int *pstack;     // m: position stack of the DFS (the reference keeps it in work1)
+    double *work;    // m, all zero between calls (work0)
+    double *xlhs;    // m, all zero between calls
+    int *ilhs;       // m: OUT pattern of the solution
+    double *xval;    // m: OUT xval[n] = lhs[ilhs[n]]
+    long long *out;  // OUT [0] nzlhs, [1] l_flops, [2] u_flops, [3] branch taken (1 sparse, 2 sequential)
+    int *lt_ptr;     // m+1   row-wise L (k_build_lt)
+    int *lt_idx;     // l_nz  row index of the pivot of the entry's column
+    double *lt_val;  // l_nz
+    int *lt_cur;     // m     scratch of k_build_lt
+};
+
+// ---- the four graphs ------------------------------------------------------------------------------
+struct GraphL {
+    static constexpr bool FILTER = false;
+    gcint_p pinv, lbeg, lidx;
+    gdouble_p lval;
+    __device__ __forceinline__ int begin(int i) const { return lbeg[pinv[i]]; }
+    __device__ __forceinline__ int end(int i) const { return lbeg[pinv[i] + 1]; }
+    __device__ __forceinline__ int node(int p) const { return lidx[p]; }
+    __device__ __forceinline__ double val(int p) const { return lval[p]; }
+    __device__ __forceinline__ double pivot(int) const { return 1.0; }
+};
+struct GraphU {
+    static constexpr bool FILTER = false;
+    gcint_p pinv, prow;
+    GPTR(const long long) colptr;
+    GPTR(const long long) rowidx;
+    GPTR(const double) value;
+    __device__ __forceinline__ int begin(int i) const { return (int)colptr[pinv[i]]; }
+    __device__ __forceinline__ int end(int i) const { return (int)colptr[pinv[i] + 1] - 1; } // pivot last
+    __device__ __forceinline__ int node(int p) const { return prow[(int)rowidx[p]]; }
+    __device__ __forceinline__ double val(int p) const { return value[p]; }
+    __device__ __forceinline__ double pivot(int i) const { return value[colptr[pinv[i] + 1] - 1]; } // row_pivot[i]
+};
+struct GraphW {
+    static constexpr bool FILTER = true;
+    gcint_p qinv, ubeg, uidx;
+    gdouble_p uval;
+    GPTR(const long long) colptr;
+    GPTR(const double) value;
+    int rank;
+    __device__ __forceinline__ int begin(int j) const
+    {
+        const int k = qinv[j];
+        return k < rank ? ubeg[k] : 0;
+    }
+    __device__ __forceinline__ int end(int j) const
+    {
+        const int k = qinv[j];
+        return k < rank ? ubeg[k + 1] : 0;
+    }
+    __device__ __forceinline__ int node(int p) const
+    {
+        const int j = uidx[p];
+        return qinv[j] < rank ? j : -1; // build_factors.rs:323
+    }
+    __device__ __forceinline__ double val(int p) const { return uval[p]; }
+    __device__ __forceinline__ double pivot(int j) const { return value[colptr[qinv[j] + 1] - 1]; } // col_pivot[j]
+};
+struct GraphLt {
+    static constexpr bool FILTER = false;
+    const int *ptr, *idx;
+    const double *v;
+    __device__ __forceinline__ int begin(int i) const { return ptr[i]; }
+    __device__ __forceinline__ int end(int i) const { return ptr[i + 1]; }
+    __device__ __forceinline__ int node(int p) const { return idx[p]; }
+    __device__ __forceinline__ double val(int p) const { return v[p]; }
+    __device__ __forceinline__ double pivot(int) const { return 1.0; }
+};
+
+// dfs (dfs.rs:49-145, after CSparse): reach of node i in topological order into xi[newtop..top), ONE lane
+template <class G>
+__device__ __forceinline__ int dfs_reach(const G &g, int i, int top, int *xi, int *pstack, int *marked, int M)
+{
+    int head = 0;
+    xi[0] = i;
+    while (head >= 0) {
+        i = xi[head];
+        if (marked[i] != M) { // node i has not been visited
+            marked[i] = M;
+            pstack[head] = g.begin(i);
+        }
+        bool done = true;
+        const int e = g.end(i);
+        for (int p = pstack[head]; p < e; p++) { // continue the search at node i
+            const int inext = g.node(p);
+            if (inext < 0 || marked[inext] == M) continue;
+            pstack[head] = p + 1;
+            xi[++head] = inext;
+            done = false;
+            break;
+        }
+        if (done) { // node i has no unvisited neighbours
+            head--;
+            xi[--top] = i;
+        }
+    }
+    return top;
+}
+
+// solve_symbolic (solve_symbolic.rs:19-40), whole wave (lane 0 works); returns top
+template <class G>
+__device__ __forceinline__ int solve_symbolic(const G &g, int m, int nrhs, const int *irhs, const SparseWs &W, int M)
+{
+    int top = m;
+    if (lane_id() == 0) {
+        for (int n = 0; n < nrhs; n++) {
+            const int i = irhs[n];
+            if (W.marked[i] != M) top = dfs_reach(g, i, top, W.psym, W.pstack, W.marked, M);
+        }
+    }
+    wave_mem_sync();
+    return __shfl(top, 0);
+}
+
+// solve_triangular (solve_triangular.rs:27-136), whole wave: columns in the given order, lanes over the
+// entries of a column.  Returns nz; pattern[0..nz) = nonzeros kept.
+template <bool PIV, class G>
+__device__ __forceinline__ int solve_triangular(const G &g, int nz_symb, const int *psym, double droptol, double *lhs, int *pattern,
+                                                long long &flops)
+{
+    const int lane = lane_id();
+    int nz = 0;
+    for (int n = 0; n < nz_symb; n++) {
+        const int ipivot = psym[n];
+        double x = lhs[ipivot];
+        if (x != 0.0) {
+            if (PIV) {
+                x = x / g.pivot(ipivot);
+                wave_mem_sync();
+                if (lane == 0) lhs[ipivot] = x;
+                flops++;
+            }
+            const int b = g.begin(ipivot), e = g.end(ipivot);
+            for (int p = b + lane; p < e; p += 64) {
+                const int i = g.node(p);
+                if (i >= 0) lhs[i] = __dsub_rn(lhs[i], __dmul_rn(x, g.val(p)));
+            }
+            if (G::FILTER) { // flop count = entries present
+                for (int p = b; p < e; p += 64) {
+                    const int q = p + lane;
+                    flops += __popcll(__ballot(q < e && g.node(q) >= 0));
+                }
+            } else {
+                flops += e - b;
+            }
+            wave_mem_sync();
+            if (fabs(x) > droptol) {
+                if (lane == 0) pattern[nz] = ipivot;
+                nz++;
+            } else if (lane == 0) {
+                lhs[ipivot] = 0.0;
+            }
+            wave_mem_sync();
+        }
+    }
+    return nz;
+}
+
+__global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, SparseWs W, int nrhs, const int *irhs, const double *xrhs,
+                                                     int trans, int marker, int nz_sparse)
+{
+    const DevG D(Ds[0]);
+    const FinishOut &O = Os[0];
+    const int lane = lane_id();
+    const int m = D.m;
+    const int rank = D.s->rank;
+    const double droptol = D.droptol;
+    long long l_flops = 0, u_flops = 0;
+    int nz = 0, branch = 1;
+    typedef GPTR(const long long) gcll;
+    typedef GPTR(const double) gcd;
+
+    if (trans) {
+        // ---- transposed system (solve_sparse.rs:51-179): U', then L'
+        const GraphW GW{D.qinv, D.ubeg, D.uidx, D.uval, (gcll)O.u_colptr, (gcd)O.u_value, rank};
+        int M = marker + 1;
+        int top = solve_symbolic(GW, m, nrhs, irhs, W, M);
+        for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
+        wave_mem_sync();
+        nz = solve_triangular<true>(GW, m - top, W.psym + top, droptol, W.work, W.pat, u_flops);
+        // permute into xlhs; the pattern goes from column to row indices (:95-106)
+        M = marker + 2;
+        for (int n = lane; n < nz; n += 64) {
+            const int j = W.pat[n], i = D.prow[D.qinv[j]]; // pmap[j]
+            W.pat[n] = i;
+            W.xlhs[i] = W.work[j];
+            W.work[j] = 0.0;
+            W.marked[i] = M;
+        }
+        wave_mem_sync();
+        const GraphLt GT{W.lt_ptr, W.lt_idx, W.lt_val};
+        if (nz <= nz_sparse) {
+            M = marker + 3;
+            top = solve_symbolic(GT, m, nz, W.pat, W, M);
+            nz = solve_triangular<false>(GT, m - top, W.psym + top, droptol, W.xlhs, W.ilhs, l_flops);
+        } else { // sequential solve with L' (:159-179)
+            branch = 2;
+            const int nin = nz;
+            (void)nin;
+            nz = 0;
+            for (int k = m - 1; k >= 0; k--) {
+                const int ipivot = D.prow[k];
+                const double x = W.xlhs[ipivot];
+                if (x != 0.0) {
+                    const int b = GT.begin(ipivot), e = GT.end(ipivot);
+                    for (int p = b + lane; p < e; p += 64) {
+                        const int i = GT.node(p);
+                        W.xlhs[i] = __dsub_rn(W.xlhs[i], __dmul_rn(x, GT.val(p)));
+                    }
+                    l_flops += e - b;
+                    wave_mem_sync();
+                    if (fabs(x) > droptol) {
+                        if (lane == 0) W.ilhs[nz] = ipivot;
+                        nz++;
+                    } else if (lane == 0) {
+                        W.xlhs[ipivot] = 0.0;
+                    }
+                    wave_mem_sync();
+                }
+            }
+        }
+    } else {
+        // ---- forward system (solve_sparse.rs:180-346): L, then U
+        const GraphL GL{D.pinv, D.lbeg, D.lidx, D.lval};
+        int M = marker + 1;
+        int top = solve_symbolic(GL, m, nrhs, irhs, W, M);
+        const int nz_symb = m - top;
+        for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
+        wave_mem_sync();
+        nz = solve_triangular<false>(GL, nz_symb, W.psym + top, droptol, W.work, W.pat, l_flops);
+        // unmark cancellation (:227-243)
+        if (nz < nz_symb && lane == 0) {
+            int t = top, n = 0;
+            while (n < nz) {
+                const int i = W.psym[t];
+                if (i == W.pat[n]) n++;
+                else W.marked[i] -= 1;
+                t++;
+            }
+            while (t < m) {
+                W.marked[W.psym[t]] -= 1;
+                t++;
+            }
+        }
+        wave_mem_sync();
+        const GraphU GU{D.pinv, D.prow, (gcll)O.u_colptr, (gcll)O.u_rowidx, (gcd)O.u_value};
+        if (nz <= nz_sparse) {
+            M = marker + 2;
+            top = solve_symbolic(GU, m, nz, W.pat, W, M);
+            nz = solve_triangular<true>(GU, m - top, W.psym + top, droptol, W.work, W.ilhs, u_flops);
+            // permute into xlhs; the pattern goes from row to column indices (:299-306)
+            for (int n = lane; n < nz; n += 64) {
+                const int i = W.ilhs[n], j = D.pcol[D.pinv[i]]; // qmap[i]
+                W.ilhs[n] = j;
+                W.xlhs[j] = W.work[i];
+                W.work[i] = 0.0;
+            }
+            wave_mem_sync();
+        } else { // sequential solve with U (:307-334)
+            branch = 2;
+            nz = 0;
+            for (int k = m - 1; k >= 0; k--) {
+                const int ipivot = D.prow[k], jpivot = D.pcol[k];
+                const double w = W.work[ipivot];
+                if (w != 0.0) {
+                    const double x = w / GU.pivot(ipivot);
+                    wave_mem_sync();
+                    if (lane == 0) W.work[ipivot] = 0.0;
+                    const int b = GU.begin(ipivot), e = GU.end(ipivot);
+                    for (int p = b + lane; p < e; p += 64) {
+                        const int i = GU.node(p);
+                        W.work[i] = __dsub_rn(W.work[i], __dmul_rn(x, GU.val(p)));
+                    }
+                    u_flops += e - b;
+                    if (fabs(x) > droptol) {
+                        if (lane == 0) {
+                            W.ilhs[nz] = jpivot;
+                            W.xlhs[jpivot] = x;
+                        }
+                        nz++;
+                    }
+                    wave_mem_sync();
+                }
+            }
+        }
+    }
+    // hand the solution out in compressed form and restore the all-zero invariant of xlhs
+    for (int n = lane; n < nz; n += 64) {
+        const int j = W.ilhs[n];
+        W.xval[n] = W.xlhs[j];
+        W.xlhs[j] = 0.0;
+    }
+    if (lane == 0) {
+        W.out[0] = nz;
+        W.out[1] = l_flops;
+        W.out[2] = u_flops;
+        W.out[3] = branch;
+    }
+}
+
+// Row-wise L in the reference's order (build_factors.rs:243-274): row i holds, for every column it has
+// an entry in, the row index of that column's pivot, ascending in the columns' pivot order.
+// One workgroup: count, scan, scatter (unordered), then sort each short row by pivot position.
+__global__ void __launch_bounds__(1024) k_build_lt(DevLU *Ds, SparseWs W)
+{
+    const DevG D(Ds[0]);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = D.m;
+    __shared__ int carry;
+    __shared__ int part[1024];
+    for (int i = tid; i < m; i += nt) W.lt_cur[i] = 0;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    const int lend = D.lbeg[m];
+    for (int p = tid; p < lend; p += nt) atomicAdd(&W.lt_cur[D.lidx[p]], 1);
+    __syncthreads();
+    // exclusive scan of the row counts, 1024 at a time
+    for (int base = 0; base < m; base += nt) {
+        const int i = base + tid;
+        const int c = i < m ? W.lt_cur[i] : 0;
+        part[tid] = c;
+        __syncthreads();
+        for (int o = 1; o < nt; o <<= 1) {
+            const int v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const int excl = carry + part[tid] - c;
+        if (i < m) {
+            W.lt_ptr[i] = excl;
+            W.lt_cur[i] = excl;
+        }
+        __syncthreads();
+        if (tid == nt - 1) carry += part[tid];
+        __syncthreads();
+    }
+    if (tid == 0) W.lt_ptr[m] = carry;
+    __syncthreads();
+    // scatter: entry (row i, stage k) -> row i, keyed by k for now
+    for (int k = tid; k < m; k += nt) {
+        for (int p = D.lbeg[k]; p < D.lbeg[k + 1]; p++) {
+            const int q = atomicAdd(&W.lt_cur[D.lidx[p]], 1);
+            W.lt_idx[q] = k;
+            W.lt_val[q] = D.lval[p];
+        }
+    }
+    __syncthreads();
+    // sort every row by k (rows are short), then replace k by the pivot row of stage k
+    for (int i = tid; i < m; i += nt) {
+        const int b = W.lt_ptr[i], e = W.lt_ptr[i + 1];
+        for (int p = b + 1; p < e; p++) {
+            const int k = W.lt_idx[p];
+            const double v = W.lt_val[p];
+            int q = p - 1;
+            while (q >= b && W.lt_idx[q] > k) {
+                W.lt_idx[q + 1] = W.lt_idx[q];
+                W.lt_val[q + 1] = W.lt_val[q];
+                q--;
+            }
+            W.lt_idx[q + 1] = k;
+            W.lt_val[q + 1] = v;
+        }
+        for (int p = b; p < e; p++) W.lt_idx[p] = D.prow[W.lt_idx[p]];
+    }
+}

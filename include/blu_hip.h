@@ -83,6 +83,8 @@ enum blu_stat {
     BLU_STAT_L_MEM = 30,
     BLU_STAT_U_MEM = 31,
     BLU_STAT_W_MEM = 32,
+    BLU_STAT_L_FLOPS = 33,       /* lu.l_flops, accumulated by solve_sparse (lu/solve_sparse.rs:356) */
+    BLU_STAT_U_FLOPS = 34,       /* lu.u_flops (:357) */
     /* device-side extras (no reference counterpart) */
     BLU_STAT_DEV_TIME_PIVOT_LOOP = 40,  /* seconds, hipEvent, last factorize */
     BLU_STAT_DEV_TIME_TOTAL = 41,       /* seconds, hipEvent, all kernels of last factorize */
@@ -129,6 +131,20 @@ int blu_hip_get_factors(blu_hip *h, int64_t *rowperm, int64_t *colperm,
 /* BLU::solve_dense -- src/blu.rs:182, src/lu/solve_dense.rs:7-120.
  * rhs and lhs may be the same array (solve_dense.rs doc, lines 14-16). */
 int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, char trans);
+
+/* solve_sparse -- src/solve_sparse.rs:36-68 (BLU::solve_sparse, src/blu.rs:207, keeps the same three
+ * outputs inside the object), lu/solve_sparse.rs:11-360 with solve_symbolic.rs, dfs.rs and
+ * solve_triangular.rs.  Right-hand side in compressed form: irhs[0..nzrhs) (no duplicates),
+ * xrhs[0..nzrhs).  `lhs` (m doubles) must be all zero on entry, as the reference requires
+ * (solve_sparse.rs:23-24); on return the solution is scattered into it, *p_nzlhs is its number of
+ * nonzeros and ilhs[0..*p_nzlhs) their indices IN THE REFERENCE'S ORDER (the topological order its
+ * depth-first searches produce, or pivot order when the sequential branch runs; parameters
+ * BLU_PARAM_SPARSE_THRES and BLU_PARAM_DROPTOL decide as in the reference).  ilhs must have room for m.
+ * Returns BLU_ERROR_INVALID_CALL without a valid factorization, BLU_ERROR_INVALID_ARGUMENT for
+ * nzrhs < 0, nzrhs > m or an index out of range.  Fresh factorizations only (no Forrest-Tomlin
+ * updates exist on this path yet). */
+int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *irhs, const double *xrhs,
+                         int64_t *p_nzlhs, int64_t *ilhs, double *lhs, char trans);
 
 /* Batch extension (no reference counterpart; the reference's only parallel
  * axis is independent BLU objects).  Factorizes n handles that

@@ -133,6 +133,11 @@ int orc_blu_get_factors(orc_blu *obj, lu_int *rowperm, lu_int *colperm,
                         lu_int *l_colptr, lu_int *l_rowidx, double *l_value,
                         lu_int *u_colptr, lu_int *u_rowidx, double *u_value); /* blu.rs:139 */
 int orc_blu_solve_dense(orc_blu *obj, const double *rhs, double *lhs, char trans); /* blu.rs:182 */
+/* BLU::solve_sparse (blu.rs:207): the solution stays in the object, as in the reference
+ * (obj.lhs dense, obj.ilhs[0..nzlhs) its pattern); the two functions below read it out. */
+int orc_blu_solve_sparse(orc_blu *obj, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, char trans);
+lu_int orc_blu_nzlhs(const orc_blu *obj);
+void orc_blu_get_lhs(const orc_blu *obj, lu_int *ilhs, double *lhs);
 orc_lu *orc_blu_lu(orc_blu *obj);
 
 /* --- procedural API (src/factorize.rs, get_factors.rs, solve_dense.rs) --- */
@@ -142,6 +147,8 @@ int orc_get_factors(orc_lu *lu, lu_int *rowperm, lu_int *colperm,
                     lu_int *l_colptr, lu_int *l_rowidx, double *l_value,
                     lu_int *u_colptr, lu_int *u_rowidx, double *u_value); /* get_factors.rs:48 */
 int orc_solve_dense(orc_lu *lu, const double *rhs, double *lhs, char trans); /* solve_dense.rs:24 */
+int orc_solve_sparse(orc_lu *lu, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, lu_int *p_nzlhs,
+                     lu_int *ilhs, double *lhs, char trans);                  /* solve_sparse.rs:36 */
 
 /* --- stats / params by key (shared numbering with include/blu_hip.h) ----- */
 double orc_get_stat(const orc_lu *lu, int key);

@@ -42,6 +42,10 @@ def lib():
         L.orc_factorize.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, _f64p, C.c_int]
         L.orc_blu_get_factors.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.orc_blu_solve_dense.argtypes = [C.c_void_p, _f64p, _f64p, C.c_char]
+        L.orc_blu_solve_sparse.argtypes = [C.c_void_p, C.c_int64, _u64p, _f64p, C.c_char]
+        L.orc_blu_nzlhs.restype = C.c_int64
+        L.orc_blu_nzlhs.argtypes = [C.c_void_p]
+        L.orc_blu_get_lhs.argtypes = [C.c_void_p, C.c_void_p, _f64p]
         L.orc_get_stat.restype = C.c_double
         L.orc_get_stat.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -141,6 +145,19 @@ class OracleBLU:
         if st != OK:
             raise RuntimeError("solve_dense status %d" % st)
         return lhs
+
+    def solve_sparse(self, irhs, xrhs, trans="N"):
+        """BLU::solve_sparse (blu.rs:207).  Returns (status, ilhs[0..nzlhs) in the reference's order, lhs dense)."""
+        ir = np.ascontiguousarray(irhs, dtype=np.uint64)
+        xr = np.ascontiguousarray(xrhs, dtype=np.float64)
+        st = lib().orc_blu_solve_sparse(self._h, len(ir), _p(ir, _u64p), _p(xr, _f64p), trans.encode()[0:1])
+        if st != OK:
+            return st, None, None
+        nz = int(lib().orc_blu_nzlhs(self._h))
+        il = np.zeros(max(1, nz), np.int64)
+        lhs = np.zeros(self.m)
+        lib().orc_blu_get_lhs(self._h, il.ctypes.data, _p(lhs, _f64p))
+        return st, il[:nz], lhs
 
     # ---- debug hooks (not in the reference) --------------------------------
     def set_stop(self, npivots):

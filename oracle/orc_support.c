@@ -410,6 +410,8 @@ double orc_get_stat(const orc_lu *lu, int key)
     case BLU_STAT_L_MEM: return (double)lu->l_mem;
     case BLU_STAT_U_MEM: return (double)lu->u_mem;
     case BLU_STAT_W_MEM: return (double)lu->w_mem;
+    case BLU_STAT_L_FLOPS: return (double)lu->l_flops;
+    case BLU_STAT_U_FLOPS: return (double)lu->u_flops;
     default: return NAN;
     }
 }

@@ -4,6 +4,8 @@ libblu_hip.so (include/blu_hip.h), against the CPU oracle and the committed gold
 Bar (BASELINE.json north_star): permutations and all integer arrays bit-exact; L/U values within
 1e-12 relative (in practice they are bit-identical: same IEEE operations in the same order).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -349,3 +351,89 @@ def test_statistics_tail_singular_and_skip(blu, oracle):
     assert h.factorize(cp[:-1], cp[1:], ri, v) == K.WARNING_SINGULAR_MATRIX
     assert h.stat(K.STAT_CONDEST_U) == 0.0
     util.assert_same_factors(h.get_factors(), o.get_factors())
+
+
+# ---- solve_sparse (src/solve_sparse.rs, lu/solve_sparse.rs, dfs.rs, solve_triangular.rs) -------------
+def _sparse_rhs(m, nz, seed):
+    rng = np.random.default_rng(seed)
+    return rng.choice(m, nz, replace=False), rng.standard_normal(nz)
+
+
+@pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1500, 8, 16, 0.2, 3, 1.0),
+                                  (6000, 10, 9, 0.5, 5, 0.3)], ids=lambda s: "m%d" % s[0])
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_solve_sparse_matches_oracle(blu, oracle, spec, trans):
+    """Pattern order (the DFS topological order / pivot order of the sequential branch), nzlhs and the
+    values are identical to the reference restatement: bit-exact, including which branch runs."""
+    cp, ri, v = oracle.gen_lp_basis(*spec)
+    m = spec[0]
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    assert sg == so == K.OK
+    branches = set()
+    for q, nz in enumerate((1, 2, 5, 17, max(1, m // 40), max(1, m // 8), m // 2)):
+        ir, xr = _sparse_rhs(m, nz, 100 * q + 7)
+        st_o, il_o, lhs_o = o.solve_sparse(ir, xr, trans)
+        st_g = g.solve_sparse(ir, xr, trans)
+        assert st_g == st_o == K.OK
+        assert g.nzlhs == len(il_o), (nz, g.nzlhs, len(il_o))
+        assert np.array_equal(g.ilhs[:g.nzlhs], il_o), nz
+        assert np.array_equal(g.lhs, lhs_o), (nz, np.abs(g.lhs - lhs_o).max())
+        branches.add(int(g.stat(43)))
+        assert g.stat(K.STAT_L_FLOPS) == o.stat(K.STAT_L_FLOPS) and g.stat(K.STAT_U_FLOPS) == o.stat(K.STAT_U_FLOPS)
+    assert 2 in branches
+    if m in (2000, 6000):
+        assert branches == {1, 2}  # both the symbolic/sparse and the sequential branch were taken
+
+
+def test_solve_sparse_solves_the_system(blu, oracle):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    m = 3000
+    cp, ri, v = oracle.gen_lp_basis(m, 9, 10, 0.4, 17, 0.4)
+    A = sp.csc_matrix((v, ri.astype(np.int64), cp.astype(np.int64)), shape=(m, m))
+    g = blu.BLU(m, len(ri))
+    assert g.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    for trans in "NT":
+        for nz in (1, 30, 900):
+            ir, xr = _sparse_rhs(m, nz, nz)
+            assert g.solve_sparse(ir, xr, trans) == K.OK
+            b = np.zeros(m)
+            b[ir] = xr
+            x = spl.spsolve(A if trans == "N" else A.T.tocsc(), b)
+            assert np.abs(g.lhs - x).max() <= 1e-10 * np.abs(x).max()
+            mask = np.zeros(m, bool)
+            mask[g.ilhs[:g.nzlhs]] = True
+            assert np.array_equal(g.lhs != 0.0, mask)
+
+
+def test_solve_sparse_rank_deficient_and_errors(blu, oracle):
+    cp, ri, v = oracle.gen_lp_basis(900, 7, 8, 0.5, 21, 0.4)
+    v = v.copy()
+    for j in (3, 77, 500, 899):
+        v[int(cp[j]):int(cp[j + 1])] *= 1e-17
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
+    assert sg == so == K.WARNING_SINGULAR_MATRIX
+    for trans in "NT":
+        for nz in (1, 6, 200):
+            ir, xr = _sparse_rhs(900, nz, 3 * nz + 1)
+            st_o, il_o, lhs_o = o.solve_sparse(ir, xr, trans)
+            assert g.solve_sparse(ir, xr, trans) == st_o == K.OK
+            assert np.array_equal(g.ilhs[:g.nzlhs], il_o) and np.array_equal(g.lhs, lhs_o)
+    assert g.solve_sparse([900], [1.0]) == K.ERROR_INVALID_ARGUMENT  # index out of range (solve_sparse.rs:49-59)
+    h = blu.BLU(10, 30)
+    assert h.solve_sparse([1], [1.0]) == K.ERROR_INVALID_CALL  # no factorization yet (solve_sparse.rs:46)
+
+
+def test_solve_sparse_golden_fixtures(blu):
+    """The HIP path against the committed fixtures (no oracle involved)."""
+    from blu_amd.matrices import simple_rs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "solve_sparse.npz"))
+    for name in ("simple", "lp2000"):
+        cp, ri, v = simple_rs()[:3] if name == "simple" else blu.gen_lp_basis(2000, 8, 8, 0.5, 1, 0.3)
+        h = blu.BLU(len(cp) - 1, len(ri))
+        assert h.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+        for n in range(int(g[name + "_ncases"])):
+            key = "%s_%d" % (name, n)
+            assert h.solve_sparse(g[key + "_irhs"], g[key + "_xrhs"], chr(int(g[key + "_trans"]))) == K.OK
+            il = h.ilhs[:h.nzlhs]
+            assert np.array_equal(il, g[key + "_ilhs"]) and np.array_equal(h.lhs[il], g[key + "_xlhs"]), key

@@ -5,6 +5,8 @@ pinned by: the known answer of examples/simple.rs, the pivot-sequence prefix
 derived by hand from the reference source, self-consistency
 (L*U == B[rowperm,colperm]) and the committed fixtures in tests/golden/.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -195,3 +197,53 @@ def test_d3_defect_is_restated_and_detected(oracle):
     assert o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
     assert o.d3_hits() > 0
     util.check_factors(cp, ri, v, o.get_factors(), tol=1e-7)
+
+
+# ---- solve_sparse --------------------------------------------------------------------
+def _golden_sparse_cases():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "solve_sparse.npz"))
+    for name in ("simple", "lp2000"):
+        for n in range(int(g[name + "_ncases"])):
+            key = "%s_%d" % (name, n)
+            yield name, chr(int(g[key + "_trans"])), g[key + "_irhs"], g[key + "_xrhs"], g[key + "_ilhs"], g[key + "_xlhs"]
+
+
+def _golden_sparse_matrix(oracle, name):
+    from blu_amd.matrices import simple_rs
+    return simple_rs()[:3] if name == "simple" else oracle.gen_lp_basis(2000, 8, 8, 0.5, 1, 0.3)
+
+
+def test_solve_sparse_golden_and_scipy(oracle):
+    """The oracle's sparse solve against its committed fixtures (pattern order included) and against
+    scipy on the same systems; the dense solve of the same object agrees to rounding."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    objs = {}
+    for name, trans, ir, xr, il_g, xl_g in _golden_sparse_cases():
+        if name not in objs:
+            cp, ri, v = _golden_sparse_matrix(oracle, name)
+            m = len(cp) - 1
+            o = oracle.OracleBLU(m, 16 * len(ri) + 64)
+            assert o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+            objs[name] = (o, sp.csc_matrix((v, ri.astype(np.int64), cp.astype(np.int64)), shape=(m, m)), m)
+        o, A, m = objs[name]
+        st, il, lhs = o.solve_sparse(ir, xr, trans)
+        assert st == K.OK and np.array_equal(il, il_g) and np.array_equal(lhs[il], xl_g)
+        mask = np.zeros(m, bool)
+        mask[il] = True
+        assert np.array_equal(lhs != 0.0, mask) and len(set(il.tolist())) == len(il)
+        b = np.zeros(m)
+        b[ir] = xr
+        x = spl.spsolve(A if trans == "N" else A.T.tocsc(), b)
+        assert np.abs(lhs - x).max() <= 1e-11 * max(1.0, np.abs(x).max())
+        assert np.abs(lhs - o.solve_dense(b, trans)).max() <= 1e-11 * max(1.0, np.abs(x).max())
+
+
+def test_solve_sparse_errors(oracle):
+    cp, ri, v = oracle.gen_lp_basis(50, 4, 4, 0.5, 1, 0.3)
+    o = oracle.OracleBLU(50, 16 * len(ri))
+    assert o.solve_sparse([1], [1.0])[0] == K.ERROR_INVALID_CALL      # solve_sparse.rs:46
+    assert o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    assert o.solve_sparse([50], [1.0])[0] == K.ERROR_INVALID_ARGUMENT  # :49-59
+    st, il, lhs = o.solve_sparse([], [])
+    assert st == K.OK and len(il) == 0 and not lhs.any()
