@@ -55,9 +55,8 @@ struct Scalars {
     long long nexpand;
     long long ngarbage;
     long long d3_hits;    // cancellations at pivot-column position >= 32 (reference defect D3 would diverge)
-    long long npivot_kind[12]; // counters: 0 singleton row, 1 singleton col, 2 doubleton, 3 small, 4 any, 5 empty col,
-                              // 6 searches served from the candidate queue, 7 searches that walked the count lists,
-                              // why: 8 queue empty, 9 fewer than maxsearch queued, 10 .. left after the purge, 11 re-entry
+    long long npivot_kind[12]; // counters: 0 singleton row, 1 singleton col, 2 doubleton, 3 small, 4 any, 5 empty col
+                              // (6..11 spare)
     double min_pivot, max_pivot;
     double onenorm, infnorm;
     double norm_l, norm_u, normest_l_inv, normest_u_inv, condest_l, condest_u, residual_test;

@@ -358,9 +358,6 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 54: return (double)s.npivot_kind[3];
     case 55: return (double)s.npivot_kind[4];
     case 56: return (double)s.npivot_kind[5];
-    case 44: case 45: case 46: case 47: return (double)s.npivot_kind[key - 36]; // why the lists were walked
-    case 48: return (double)s.npivot_kind[6]; // searches served from the candidate queue
-    case 49: return (double)s.npivot_kind[7]; // searches that walked the count lists
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
     case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:

@@ -1215,8 +1215,9 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->nexpand = 0;
         sm->d3 = 0;
         sm->stop_at = stop_at;
-        sm->fa.qN = 0;
         sm->fa.kind = 0;
+        sm->fa.ewFlag = 0;
+        sm->fa.ewValid = 0;
         for (int k = 0; k < 12; k++) sm->kinds[k] = 0;
         for (int k = 0; k < 48; k++) sm->prof[k] = 0;
     }
@@ -1274,8 +1275,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
             __syncthreads(); // every thread has read sm->pr / sm->pc before thread 0 rewrites them
             if (tid == 0) {
                 list_remove1(D.cflink, D.cblink, pc);
-                sm->fa.qN = 0;
-                sm->pc = -1;
+                        sm->pc = -1;
                 sm->rankdef++;
                 sm->kinds[5]++;
             }
@@ -1326,6 +1326,13 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
                 sm->prof[38] += g_pstamp[37] - g_pstamp[36]; // third task done
                 sm->prof[39] += g_pstamp[38] - g_pstamp[37]; // all of wave 1's tasks done, stores drained
                 sm->prof[40] += g_pstamp[3] - g_pstamp[38];  // ... until every wave is past the barrier
+                if (g_pstamp[44] > g_pstamp[3]) { // early search of the next pivot, relative to stamp 3
+                    sm->prof[41] += g_pstamp[41] - g_pstamp[3];  // entered (preconditions, min of the new counts)
+                    sm->prof[42] += g_pstamp[42] - g_pstamp[41]; // waited for the list wave's pairs
+                    sm->prof[43] += g_pstamp[43] - g_pstamp[42]; // walk
+                    sm->prof[44] += g_pstamp[44] - g_pstamp[43]; // staging (or the express loads)
+                    sm->prof[45] += 1;
+                }
             }
             if (kk != 3) { // stages of the flattened search (stamps 8..14 set inside markowitz_fast)
                 sm->prof[8] += g_pstamp[8] - g_pstamp[0];   // head barrier -> search entered
@@ -1359,8 +1366,6 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
                     if (D.colmax[j] == 0.0 || D.colmax[j] < D.abstol) remove_col_serial(D, sm, j);
                 }
             }
-            // the candidate queue survives only pivots whose column set is in the LDS hash (k_pivot_fast.hip)
-            if (sm->fa.kind == 0 || sm->flag_small) sm->fa.qN = 0;
             sm->flops += (long long)(nz_col - 1) * (long long)(nz_row - 1);
             D.pinv[pr] = rank;
             D.qinv[pc] = rank;

@@ -126,10 +126,12 @@ struct InHRow {
 template <class InSet>
 __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
                                         InSet inS, int big, int gone, int *scratch /* 320 ints of LDS */,
-                                        unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
+                                        unsigned long long *kg /* KGMAX words of LDS, all zero between calls */,
+                                        Fast *pub /* or null: publish the unlinked runs for early_search */, int seq = 0)
 {
     const int lane = lane_id();
     int minkey = big;
+    if (pub && n >= 64 && lane == 0) __hip_atomic_store(&pub->ewFlag, -seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (n < 64) {
         // Single pass, one memory round trip.  Lane n unlinks `gone`.
         // Single pass: the three loads per element (its two links and the tail of its new list) are
@@ -205,6 +207,17 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
                 fp = fp2;
                 pl = pl2;
             }
+        }
+        if (pub) { // the searching wave walks the lists while these stores are under way: tell it the new links
+            const unsigned long long fm = __ballot(first);
+            if (first) {
+                const int d = __popcll(fm & lanes_below(lane));
+                pub->ewP[d] = p;
+                pub->ewF[d] = fs;
+            }
+            if (lane == 0) pub->ewNP = __popcll(fm);
+            wave_mem_sync();
+            if (lane == 0) __hip_atomic_store(&pub->ewFlag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (first) { // link the run's unmoved predecessor to its unmoved successor
             flink[p] = fs;
@@ -299,10 +312,6 @@ __device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
     if (K < 1 || K > KCMAX || m >= (1 << 27)) return 3; // (cost*256 + position must fit 64 bits)
-    if (lane == 0) {
-        sm->kinds[7]++;
-        fa->qN = 0;
-    }
     const int h0 = D.cflink[m];
     if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
         if (lane == 0) {
@@ -313,7 +322,6 @@ __device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
     }
     int ncand = 0, total = 0;
     int nz = sm->min_colnz;
-    int lastfl = -1, lastnz = 0;
     bool bad = false;
     while (ncand < K && nz <= m && !bad) {
         const int k = nz + lane;
@@ -348,18 +356,9 @@ __device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
                     fa->cL[ncand] = cl;
                     fa->cMx[ncand] = cmx;
                     fa->cOff[ncand] = total;
-                    if (BLU_QUEUE) { // the walk also (re)starts the candidate queue
-                        fa->qJ[ncand] = j;
-                        fa->qNz[ncand] = znz;
-                        fa->qB[ncand] = cb;
-                        fa->qL[ncand] = cl;
-                        fa->qMx[ncand] = cmx;
-                    }
                 }
                 total += cl;
                 ncand++;
-                lastfl = fl;
-                lastnz = znz;
                 j = fl;
             }
         }
@@ -376,170 +375,10 @@ __device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
     if (lane == 0) {
         fa->cOff[ncand] = total;
         fa->ncand = ncand;
-        if (BLU_QUEUE) {
-            fa->qN = ncand;
-            fa->qCont = lastfl; // >= m: end of list lastnz, as of this search
-            fa->qContNz = lastnz;
-        }
     }
     wave_mem_sync();
     if (total > STGMAX) return 3;
     return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Candidate queue.  The walk above costs one dependent memory round trip per candidate; but the
-// leading columns of the count lists change little from pivot to pivot: the columns of the last pivot
-// row leave (they are re-appended at the tails of their new lists), everything else keeps its place.
-// So the first columns in search order are kept in LDS across pivots:
-//   * after a pivot handled by the paths of this file, q_prepare drops the members of that pivot's
-//     column set from the queue; the rest is still a prefix of the search order provided no moved column
-//     re-entered before the queue's end, i.e. min(new counts) >= count of the last queued column
-//     (an equal count is appended behind every older member of that list);
-//   * any other event (general pivot paths, removed or empty columns, relaunch) empties the queue and
-//     the next search walks the lists;
-//   * the queue is topped up while the search waits for its own loads (QRef below): one element per
-//     step, read through the successor link of the last queued column.
-// The unmoved columns' (begin, len, max) cannot change, so no queued value goes stale.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int q_prepare(const DevG &D, Sm *sm)
-{
-    const int lane = lane_id();
-    Fast *fa = &sm->fa;
-    const int K = D.maxsearch;
-    if (!BLU_QUEUE) return 2;
-    const int n = fa->qN;
-    if (n < K || K < 1 || K > KCMAX) {
-        if (lane == 0) sm->kinds[n == 0 ? 8 : 9]++;
-        return 2;
-    }
-    const int j = lane < n ? fa->qJ[lane] : -1;
-    const int jnz = lane < n ? fa->qNz[lane] : 0, jb = lane < n ? fa->qB[lane] : 0, jl = lane < n ? fa->qL[lane] : 0;
-    const double jmx = lane < n ? fa->qMx[lane] : 0.0;
-    const bool keep = lane < n && !hcol_has(fa, j);
-    const unsigned long long kb = __ballot(keep);
-    const int nn = __popcll(kb);
-    if (nn < K) {
-        if (lane == 0) sm->kinds[10]++;
-        return 2;
-    }
-    const int lastl = 63 - __clzll((long long)kb);
-    if (fa->qMinNew < __shfl(jnz, lastl)) {
-        if (lane == 0) sm->kinds[11]++;
-        return 2;
-    }
-    const int cont = fa->qCont;
-    // the known successor may be the head of a LATER list (qContNz > count of the last queued column):
-    // a column re-appended to a list in between would come first
-    const bool contok = lastl == n - 1 && cont >= 0 && cont < D.m && !hcol_has(fa, cont) && fa->qMinNew >= fa->qContNz;
-    wave_mem_sync();
-    const int d = __popcll(kb & lanes_below(lane));
-    if (keep) {
-        fa->qJ[d] = j;
-        fa->qNz[d] = jnz;
-        fa->qB[d] = jb;
-        fa->qL[d] = jl;
-        fa->qMx[d] = jmx;
-    }
-    // the first K become this search's candidates
-    if (keep && d < K) {
-        fa->cJ[d] = j;
-        fa->cNz[d] = jnz;
-        fa->cB[d] = jb;
-        fa->cL[d] = jl;
-        fa->cMx[d] = jmx;
-    }
-    wave_mem_sync();
-    if (lane == 0) {
-        int tot = 0;
-        for (int i = 0; i < K; i++) {
-            fa->cOff[i] = tot;
-            tot += fa->cL[i];
-        }
-        fa->cOff[K] = tot;
-        fa->ncand = K;
-        fa->qN = nn;
-        if (!contok) fa->qCont = -1;
-    }
-    wave_mem_sync();
-    if (fa->cOff[K] > STGMAX) return 3;
-    return 0;
-}
-
-// one pending top-up load of the queue; all members are wave-uniform except h
-struct QRef {
-    int kind; // 0 none, 1 (count, begin, len, max, link) of column x, 2 successor link of the last column, 3 list heads
-    int x, nz, fl, cb, cl, h;
-    double mx;
-};
-__device__ __forceinline__ void qref_issue(const DevG &D, Fast *fa, QRef &r)
-{
-    r.kind = 0;
-    const int n = fa->qN, m = D.m;
-    if (!BLU_QUEUE || n <= 0 || n >= QMAX) return;
-    const int cont = fa->qCont;
-    if (cont >= 0 && cont < m) {
-        r.kind = 1;
-        r.x = cont;
-        r.nz = fa->qContNz;
-        r.fl = D.cflink[cont];
-        r.cb = D.cbeg[cont];
-        r.cl = D.clen[cont];
-        r.mx = D.colmax[cont];
-    } else if (cont < 0) {
-        r.kind = 2;
-        r.nz = fa->qNz[n - 1];
-        r.fl = D.cflink[fa->qJ[n - 1]];
-    } else { // end of list qContNz: first element of the next non-empty list within 64 counts
-        r.kind = 3;
-        r.nz = fa->qContNz + 1;
-        const int k = r.nz + lane_id();
-        r.h = k <= m ? D.cflink[m + k] : m + k;
-    }
-}
-__device__ __forceinline__ void qref_consume(const DevG &D, Fast *fa, QRef &r)
-{
-    const int lane = lane_id(), m = D.m;
-    if (r.kind == 0) return;
-    if (r.kind == 1) {
-        // a column that fails these checks stops the top-up; the list walk raises the error when it gets there
-        const bool good = r.cl == r.nz && r.mx != 0.0 && r.mx >= D.abstol;
-        if (lane == 0) {
-            if (good) {
-                const int n = fa->qN;
-                fa->qJ[n] = r.x;
-                fa->qNz[n] = r.nz;
-                fa->qB[n] = r.cb;
-                fa->qL[n] = r.cl;
-                fa->qMx[n] = r.mx;
-                fa->qN = n + 1;
-                fa->qCont = r.fl;
-                fa->qContNz = r.nz;
-            } else {
-                fa->qCont = -1;
-            }
-        }
-    } else if (r.kind == 2) {
-        if (lane == 0) {
-            fa->qCont = r.fl;
-            fa->qContNz = r.nz;
-        }
-    } else {
-        const int k = r.nz + lane;
-        const unsigned long long ne = __ballot(k <= m && r.h != m + k);
-        if (ne) {
-            const int b = __ffsll((long long)ne) - 1;
-            const int x = __shfl(r.h, b);
-            if (lane == 0) {
-                fa->qCont = x;
-                fa->qContNz = r.nz + b;
-            }
-        } else if (lane == 0) {
-            fa->qCont = -1;
-        }
-    }
-    r.kind = 0;
-    wave_mem_sync();
 }
 
 __device__ __forceinline__ void mk_stage(const DevG &D, Sm *sm, long long &mcb, int &fb)
@@ -630,13 +469,12 @@ __device__ __forceinline__ bool mk_express(const DevG &D, Sm *sm, int &nsearched
         fa->sB[0] = rb;
         fa->sL[0] = rl;
         fa->sC[0] = rc;
-        if (BLU_QUEUE) fa->qN = 0;
     }
     wave_mem_sync();
     return true;
 }
 
-__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, QRef &qr, int nsearched)
+__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, int nsearched)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -718,8 +556,6 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
         return;
     }
     PROF_STAMP(12); // pivot column copied, pivot row loaded
-    qref_consume(D, fa, qr); // (its loads were issued before those of the pivot row: no extra wait)
-    qref_issue(D, fa, qr);
     for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
     for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
     long long gc = 0, gr = 0;
@@ -742,7 +578,6 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
         }
     }
     PROF_STAMP(13); // line metadata of the pivot row's columns loaded, column hash built
-    qref_consume(D, fa, qr);
     if (kind == 1) {
         for (int p = 1 + lane; p < nzc; p += 64) {
             hrow_insert(fa, fa->pcI[p], p);
@@ -769,75 +604,64 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
     if (lane_id() == 0) fa->kind = 0;
     PROF_STAMP(8);
     int nsr = 0;
+    if (BLU_EARLY && fa->ewValid) { // found and staged while the previous pivot was being finished (early_search)
+        const int lane = lane_id();
+        const long long mcb = fa->ewMcb[lane];
+        const int fb = fa->ewFb[lane];
+        nsr = fa->ewNsr;
+        wave_mem_sync();
+        if (lane == 0) fa->ewValid = 0;
+#ifdef BLU_EWCHECK
+        { // self-checking build: the ordinary search must give the same candidates, costs and count
+            const int sN = fa->ncand;
+            const int myc = lane < sN ? fa->cJ[lane] : -1;
+            wave_mem_sync();
+            int nsr2 = 0, fb2 = 0;
+            long long mcb2 = 0;
+            bool okc = true;
+            if (!mk_express(D, sm, nsr2)) {
+                const int r2 = mk_walk(D, sm);
+                if (r2 == 0) {
+                    mk_stage(D, sm, mcb2, fb2);
+                    nsr2 = fa->ncand;
+                } else {
+                    okc = false;
+                }
+            }
+            okc = okc && fa->ncand == sN && nsr2 == nsr && mcb2 == mcb && fb2 == fb && (lane >= sN || fa->cJ[lane] == myc);
+            if (__ballot(!okc)) {
+                if (lane == 0 && D.s->prof[0] == 0) {
+                    long long *P = D.s->prof;
+                    P[0] = 1 + sm->rank;
+                    P[1] = sN * 10 + fa->ncand;
+                    P[2] = nsr * 10 + nsr2;
+                    for (int i = 0; i < 3; i++) P[7 + i] = fa->cJ[i] * 1000LL + fa->cNz[i];
+                }
+                if (lane < 3) D.s->prof[10 + lane] = myc;
+                DEV_CHECK(D.s, false);
+            }
+        }
+#endif
+        PROF_STAMP(9);
+        PROF_STAMP(10);
+        mk_pick(D, sm, mcb, fb, nsr);
+        return true;
+    }
     if (mk_express(D, sm, nsr)) {
         PROF_STAMP(9);
         PROF_STAMP(10);
-        QRef q0;
-        q0.kind = 0;
-        mk_pick(D, sm, 0, 0, q0, nsr);
+        mk_pick(D, sm, 0, 0, nsr);
         return true;
     }
-    int r = q_prepare(D, sm);
-    if (r == 2) {
-        r = mk_walk(D, sm);
-    } else {
-        if (lane_id() == 0) sm->kinds[6]++;
-#ifdef BLU_QCHECK
-        // self-checking build (`make qcheck`): every answer of the queue is compared with a walk of the
-        // lists; the queue itself is put back afterwards so that its evolution is the product's
-        const int lane = lane_id(), K = D.maxsearch;
-        const int sJ = lane < QMAX ? fa->qJ[lane] : 0, sNz = lane < QMAX ? fa->qNz[lane] : 0, sB = lane < QMAX ? fa->qB[lane] : 0,
-                  sL = lane < QMAX ? fa->qL[lane] : 0;
-        const double sMx = lane < QMAX ? fa->qMx[lane] : 0.0;
-        const int sN = fa->qN, sCont = fa->qCont, sContNz = fa->qContNz;
-        const int myc = lane < K ? fa->cJ[lane] : -1;
-        wave_mem_sync();
-        const int r2 = mk_walk(D, sm);
-        const bool same = r2 == r && (lane >= K || fa->cJ[lane] == myc);
-        if (__ballot(!same)) {
-            if (lane == 0 && D.s->prof[0] == 0) { // first mismatch: what the queue said / what the lists say
-                long long *P = D.s->prof;
-                P[0] = 1 + sm->rank;
-                P[1] = r * 10 + r2;
-                P[2] = sN;
-                P[3] = fa->qMinNew;
-                P[4] = sCont;
-                P[5] = sContNz;
-                P[6] = sm->min_colnz;
-                for (int i = 0; i < 3; i++) P[7 + i] = fa->cJ[i] * 1000LL + fa->cNz[i];
-            }
-            if (lane < 3) D.s->prof[10 + lane] = myc * 1000LL + sNz; // (sNz of the purged queue's first entries)
-            DEV_CHECK(D.s, false);
-        }
-        wave_mem_sync();
-        if (lane < QMAX) {
-            fa->qJ[lane] = sJ;
-            fa->qNz[lane] = sNz;
-            fa->qB[lane] = sB;
-            fa->qL[lane] = sL;
-            fa->qMx[lane] = sMx;
-        }
-        if (lane == 0) {
-            fa->qN = sN;
-            fa->qCont = sCont;
-            fa->qContNz = sContNz;
-            sm->kinds[7]--;
-        }
-        wave_mem_sync();
-#endif
-    }
-    PROF_STAMP(9); // candidates known (from the queue, or list heads + up to K link/meta loads)
+    const int r = mk_walk(D, sm);
+    PROF_STAMP(9); // candidates walked (list heads + up to K link/meta loads)
     if (r == 3) return false;
     if (r != 0) return true; // empty column chosen, or error raised
-    QRef qr;
-    qref_issue(D, fa, qr); // queue top-ups ride on the waits of the search's own loads
     long long mcb;
     int fb;
     mk_stage(D, sm, mcb, fb);
     PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
-    qref_consume(D, fa, qr);
-    qref_issue(D, fa, qr);
-    mk_pick(D, sm, mcb, fb, qr, fa->ncand);
+    mk_pick(D, sm, mcb, fb, fa->ncand);
     return true;
 }
 
@@ -963,6 +787,8 @@ __device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *w
         D.ccap[j] = newcap;
         D.colmax[j] = cmx;
         fa->tNew[q] = newlen;
+        fa->tB[q] = dst;  // (new begin and maximum: the early search of the next pivot reads them)
+        fa->tMx[q] = cmx;
         fa->tX[q] = xrj;
         fa->tM[q] = mask;
         if (mask) fa->anycancel = 1;
@@ -1120,6 +946,213 @@ __device__ __forceinline__ void fast_write_l(const DevG &D, Sm *sm)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Early search: the candidates of pivot k+1, found and staged by wave 0 WHILE the other waves finish
+// pivot k (U/L write-out, count-list update).  After the line updates of pivot k (barrier) everything
+// the next search reads is final -- column entries, line metadata -- except the count lists, which
+// the list wave is rewriting at that very moment.  The lists AFTER the update are nevertheless known:
+//   * an unmoved column keeps its place; its successor is the next unmoved one.  The list wave
+//     publishes, for every run of moved neighbours it unlinks, (unmoved predecessor or list head ->
+//     first unmoved successor); any other unmoved column's link in memory is not touched by the unlink
+//     stores;
+//   * the moved columns are re-appended behind ALL unmoved members of the list of their new count, in
+//     pivot-row order: their keys and order are in LDS (elems / keys).  A moved column met while
+//     following a link in memory is therefore an appended one: the unmoved part of that list has ended.
+// So the first maxsearch columns in search order are: for count c ascending, the unmoved members of list
+// c (links through memory, corrected by the published pairs), then the moved columns with new count c.
+// Not attempted (the ordinary search runs): a column became empty or numerically null, a cancellation
+// fix-up is pending, row search is on, the batch took the long path, fewer than 4 waves.
+// `make ewcheck` compares every early result with the ordinary search.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void early_search(const DevG &D, Sm *sm, const int *elems, const int *keys, const int *begs, const double *maxs,
+                                             int n)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (!BLU_EARLY || D.search_rows || D.no_fast || K < 1 || K > KCMAX || m >= (1 << 27) || n >= 64) return;
+    if (sm->flag_small || fa->anycancel) return;
+    const int left = m - (sm->rank + 1) - sm->rankdef; // active columns at the next search
+    if (left < 1) return;
+    // my moved column (lane q < n): new count, new begin, new maximum -- all in LDS since the line updates
+    const int kq = lane < n ? keys[lane] : -1;
+    const int minnew = wave_min_i(kq >= 0 ? kq : m + 2);
+    if (minnew == 0) return; // an empty column: the ordinary search takes it (markowitz.rs:73-78)
+    int nz = sm->min_colnz < minnew ? sm->min_colnz : minnew;
+    if (nz < 1) nz = 1;
+
+    // ---- before the list wave has anything to say: the heads of 64 lists, which of these lists receive
+    // moved columns, and the metadata of the first column in line if that one is not moved (its place
+    // does not depend on the update)
+    const int k = nz + lane;
+    int h = k <= m ? D.cflink[m + k] : m + k;
+    if (lane == 0) fa->ewMask = 0ull;
+    wave_mem_sync();
+    if (kq >= nz && kq < nz + 64) atomicOr(&fa->ewMask, 1ull << (kq - nz));
+    wave_mem_sync();
+    const unsigned long long mv = fa->ewMask;
+    const bool hm = k <= m && h < m && hcol_has(fa, h); // first member moved: the list wave knows the new first one
+    const unsigned long long amb = __ballot(hm);
+    const unsigned long long um0 = __ballot(k <= m && h < m && !hm);
+    int j0 = -1, fl0 = 0, cb0 = 0, cl0 = 0;
+    double cmx0 = 0.0;
+    {
+        const unsigned long long any = um0 | amb | mv;
+        if (any) {
+            const int b0 = __ffsll((long long)any) - 1;
+            if ((um0 >> b0) & 1ull) {
+                j0 = __shfl(h, b0);
+                fl0 = D.cflink[j0];
+                cb0 = D.cbeg[j0];
+                cl0 = D.clen[j0];
+                cmx0 = D.colmax[j0];
+            }
+        }
+    }
+    PROF_STAMP(41);
+    // ---- the list wave's pairs (unmoved predecessor or head -> first unmoved successor)
+    // (the flag carries the number of the pivot it belongs to: no reset, no stale value)
+    const int seq = sm->rank + 1;
+    int flag;
+    while ((flag = __hip_atomic_load(&fa->ewFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq && flag != -seq)
+        __builtin_amdgcn_s_sleep(1);
+    if (flag < 0) return;
+    PROF_STAMP(42);
+    const int np = fa->ewNP;
+    const int myP = lane < np ? fa->ewP[lane] : -1, myF = lane < np ? fa->ewF[lane] : 0;
+    if (amb) { // heads whose first member was moved
+        int *win = fa->ls[1]; // 64 ints (scratch of the row-list batch: row search is off here)
+        win[lane] = -2;
+        wave_mem_sync();
+        if (myP >= m + nz && myP < m + nz + 64) win[myP - m - nz] = myF;
+        wave_mem_sync();
+        if (hm) h = win[lane] != -2 ? win[lane] : m + k; // (a head with a moved first member is always a predecessor)
+    }
+    const unsigned long long um = __ballot(k <= m && h < m);
+    unsigned long long ne = um | mv;
+    int ncand = 0, total = 0;
+    bool bad = false, express = false;
+    while (ne && ncand < K && !bad && !express) {
+        const int b = __ffsll((long long)ne) - 1;
+        ne &= ne - 1;
+        const int c = nz + b;
+        if ((um >> b) & 1ull) { // unmoved members of list c
+            int j = __shfl(h, b);
+            int guard = 0;
+            while (j < m && ncand < K) {
+                int fl, cb, cl;
+                double cmx;
+                if (j == j0) {
+                    fl = fl0;
+                    cb = cb0;
+                    cl = cl0;
+                    cmx = cmx0;
+                } else {
+                    fl = D.cflink[j];
+                    cb = D.cbeg[j];
+                    cl = D.clen[j];
+                    cmx = D.colmax[j];
+                }
+                if (cl != c || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > 8) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = c;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = cl;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                total += cl;
+                ncand++;
+                if (ncand == 1 && c == 1) {
+                    express = true;
+                    break;
+                }
+                const unsigned long long hit = __ballot(myP == j);
+                int nx = hit ? __builtin_amdgcn_readlane(myF, __ffsll((long long)hit) - 1) : fl;
+                if (nx < m && hcol_has(fa, nx)) nx = m + c; // an appended column: the unmoved part ends here
+                j = nx;
+            }
+        }
+        if (((mv >> b) & 1ull) && !bad && !express) { // then the moved columns whose new count is c, in pivot-row order
+            unsigned long long qb = __ballot(kq == c);
+            while (qb && ncand < K) {
+                const int l = __ffsll((long long)qb) - 1;
+                qb &= qb - 1;
+                const int j = elems[l], cb = begs[l];
+                const double cmx = maxs[l];
+                if (cmx == 0.0 || !(cmx >= D.abstol)) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = c;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = c;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                total += c;
+                ncand++;
+                if (ncand == 1 && c == 1) {
+                    express = true;
+                    break;
+                }
+            }
+        }
+    }
+    PROF_WAIT();
+    PROF_STAMP(43);
+    // fewer than maxsearch columns in this window of 64 counts: leave it to the ordinary search, unless
+    // these are all the columns there are
+    if (bad || ncand == 0 || (!express && ncand < K && ncand < left)) return;
+    int nsr;
+    long long mcb = 0;
+    int fb = 0;
+    if (express) { // column singleton first in line: mk_express's answer
+        const int cb = fa->cB[0];
+        const double cmx = fa->cMx[0];
+        const int idx = D.cidx[cb];
+        const double val = D.cval[cb];
+        const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+        const double tol = fmax(D.abstol, D.reltol * cmx);
+        const double x = fabs(val);
+        if (x == 0.0 || x < tol) return;
+        nsr = left < K ? left : K;
+        if (lane == 0) {
+            fa->ncand = 1;
+            fa->cOff[1] = 1;
+            fa->sI[0] = idx;
+            fa->sV[0] = val;
+            fa->sB[0] = rb;
+            fa->sL[0] = rl;
+            fa->sC[0] = rc;
+        }
+    } else {
+        if (total > STGMAX) return;
+        if (lane == 0) {
+            fa->cOff[ncand] = total;
+            fa->ncand = ncand;
+        }
+        wave_mem_sync();
+        mk_stage(D, sm, mcb, fb);
+        nsr = ncand;
+    }
+    PROF_STAMP(44);
+    fa->ewMcb[lane] = mcb;
+    fa->ewFb[lane] = fb;
+    if (lane == 0) {
+        fa->ewNsr = nsr;
+        fa->ewValid = 1;
+    }
+    wave_mem_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc, int nzc, int nzr)
@@ -1201,7 +1234,12 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
         for (int p = 1 + w; p <= cnz1; p += nw) fast_fixrow(D, sm, p);
         __syncthreads();
     }
-    if (w == 0) {
+    // finalize step, one job per wave: [0] the search of the NEXT pivot (early_search), [1] L column,
+    // [2] count lists, [3] U row and the pivot's own bookkeeping; with fewer than 4 waves (or row search)
+    // wave 0 writes the U row instead and the next search waits for the barrier
+    const bool early = BLU_EARLY && nw >= 4 && !D.search_rows;
+    if (w == 0 && early) early_search(D, sm, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1);
+    if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
         if (lane == 0) {
             D.colmax[pc] = fa->pcV[0];
@@ -1209,11 +1247,7 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
             D.rlen[pr] = 0;
             sm->kinds[3]++;
         }
-        if (BLU_QUEUE) {
-            const int mnew = wave_min_key(fa->tNew + 1, rnz1, m + 2);
-            if (lane == 0) fa->qMinNew = mnew;
-        }
-        PROF_STAMP(6);
+        PROF_STAMP_L0(6);
     }
     if (w == 1 % nw) {
         fast_write_l(D, sm);
@@ -1221,7 +1255,8 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
     }
     if (w == 2 % nw) {
         PROF_STAMP_L0(25);
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->ls[0], fa->kg[0]);
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->ls[0], fa->kg[0],
+                                                early ? fa : nullptr, sm->rank + 1);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
         PROF_WAIT();
         PROF_STAMP_L0(29);
@@ -1229,7 +1264,8 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
     if (D.search_rows && w == 3 % nw) {
         if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1], fa->kg[1]);
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1], fa->kg[1],
+                                                (Fast *)nullptr);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
     __syncthreads();
@@ -1278,12 +1314,16 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc,
             D.clen[j] = cl - 1;
             D.colmax[j] = cmx;
             fa->tNew[q] = cl - 1;
+            fa->tMx[q] = cmx;
             fa->tX[q] = xrj;
             if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
         }
     }
     __syncthreads();
-    if (w == 0) {
+    // finalize step: [0] the search of the next pivot, [1] count lists, [2] U row and bookkeeping
+    const bool early = BLU_EARLY && nw >= 4 && !D.search_rows;
+    if (w == 0 && early) early_search(D, sm, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl);
+    if (w == (early ? 2 : 0)) {
         fast_write_u(D, sm, 0, rl - 1, wq);
         if (lane == 0) {
             D.lbeg[sm->rank + 1] = sm->lused; // empty column in L
@@ -1292,15 +1332,12 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc,
             D.rlen[pr] = 0;
             sm->kinds[1]++;
         }
-        if (BLU_QUEUE) {
-            const int mnew = wave_min_key(fa->tNew, rl, m + 2);
-            if (lane == 0) fa->qMinNew = mnew;
-        }
     }
     if (w == 1 % nw) {
         if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
         // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->ls[0], fa->kg[0]);
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->ls[0], fa->kg[0],
+                                                early ? fa : nullptr, sm->rank + 1);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
     }
     __syncthreads();

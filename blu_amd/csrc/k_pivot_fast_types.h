@@ -9,12 +9,14 @@
 #define KGMAX 256    // batched list moves: keys (new counts) below this meet in an LDS table
 #define HROW_BITS 8
 #define HCOL_BITS 9
-#define QMAX 8      // candidate queue: leading columns of the count lists kept across pivots
-// The queue is compiled out by default: on banded LP bases most queued columns sit in the very next
-// pivot row (24 % of the searches of the 100k benchmark basis were served from it, the top-up loads
-// cost more than those saved).  -DBLU_QUEUE=1 enables it, `make qcheck` verifies it against the lists.
-#ifndef BLU_QUEUE
-#define BLU_QUEUE 0
+// Early search (early_search in k_pivot_fast.hip): wave 0 finds and stages the candidates of pivot k+1
+// while the other waves finish pivot k.  Correct (`make ewcheck` verifies every early result against the
+// ordinary search) but compiled out by default: the list update must publish its unlinked runs before
+// the walk can follow a link, so the early search ends ~12 000 cycles after the barrier where the
+// finalize step alone takes ~5 000 and the ordinary walk + staging ~4 200: 900 -> 972 ms on the 100k
+// benchmark basis.  -DBLU_EARLY=1 enables it.
+#ifndef BLU_EARLY
+#define BLU_EARLY 0
 #endif
 
 struct Fast {
@@ -24,18 +26,18 @@ struct Fast {
     int ncand;
     int cJ[KCMAX], cNz[KCMAX], cB[KCMAX], cL[KCMAX], cOff[KCMAX + 1];
     double cMx[KCMAX];
-    // candidate queue (see q_prepare in k_pivot_fast.hip): the first qN active columns in search order
-    // (count lists 1,2,.. each from its head), with their (count, begin, len, max).  qCont = successor of
-    // the last one in its list if known (>= m: end of list qContNz seen during this search; -1 unknown).
-    int qN, qCont, qContNz, qMinNew;
-    int qJ[QMAX], qNz[QMAX], qB[QMAX], qL[QMAX];
-    double qMx[QMAX];
+    // early search: hand-over from the list wave (unlinked runs: predecessor -> first unmoved successor)
+    // and the result kept for the next search
+    int ewFlag, ewNP, ewValid, ewNsr;
+    unsigned long long ewMask;
+    int ewP[64], ewF[64], ewFb[64];
+    long long ewMcb[64];
     // pivot column, pivot at slot 0 (kind 1), with the (begin,len,cap) of each row
     int pcI[PCMAX], prB[PCMAX], prL[PCMAX], prC[PCMAX], rNew[PCMAX], rKept[PCMAX], rDst[PCMAX];
     double pcV[PCMAX];
     // pivot row, pivot column at slot 0 (kind 1), with the (begin,len,cap) of each column
     int tJ[PRMAX], tB[PRMAX], tL[PRMAX], tC[PRMAX], tNew[PRMAX];
-    double tX[PRMAX];
+    double tX[PRMAX], tMx[PRMAX]; // pivot-row value of the column; its new maximum
     unsigned long long tM[PRMAX];
     // staged candidate entries
     int sI[STGMAX], sB[STGMAX], sL[STGMAX], sC[STGMAX];

@@ -15,7 +15,6 @@ for rep in range(2):
 p = [h.stat(60 + k) for k in range(48)]
 tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
 tot = sum(p[:4])
-print("searches served from the candidate queue: %d, list walks: %d (queue empty %d, short %d, short after purge %d, re-entry %d)" % tuple(h.stat(k) for k in (48, 49, 44, 45, 46, 47)))
 if tot == 0:
     print("status", st, "t_pivot %.1f ms (not a diagnostic build: no phase ticks)" % (1e3 * tp))
     sys.exit(0)
@@ -38,3 +37,6 @@ print("fast small, finalize step (cycles after the barrier): U row written @%.0f
       % (cyc(22), cyc(23), cyc(24), cyc(25), cyc(26), cyc(27), cyc(28), cyc(29)))
 print("fast small, line updates as wave 1 sees them: %.1f column + %.1f row tasks per pivot; cycles: loads issued %.0f | arrived %.0f | task 1 %.0f | task 2 %.0f | task 3 %.0f | rest + drain %.0f | waiting for the others %.0f"
       % (cyc(32), cyc(33), cyc(34), cyc(35), cyc(36), cyc(37), cyc(38), cyc(39), cyc(40)))
+ne = max(1, p[45])
+print("early search of the next pivot, after fast small pivots (%d of %d): enters @%.0f | waits for the pairs %.0f | walk %.0f | staging %.0f cycles"
+      % (p[45], n1, p[41] / ne, p[42] / ne, p[43] / ne, p[44] / ne))
