@@ -490,6 +490,43 @@ extern "C" int blu_hip_get_factors(blu_hip *h, int64_t *rowperm, int64_t *colper
     return ok ? BLU_OK : BLU_ERROR_DEVICE;
 }
 
+// workspace of the solves that walk the factors line by line (allocated at the first use)
+static int ensure_sparse_ws(blu_hip *h)
+{
+    if (h->sw_ready) return BLU_OK;
+    const size_t M = (size_t)h->m;
+    SparseWs &W = h->sw;
+    bool a = dalloc(h, &W.marked, M) && dalloc(h, &W.psym, M) && dalloc(h, &W.pat, M) && dalloc(h, &W.pstack, M) &&
+             dalloc(h, &W.work, M) && dalloc(h, &W.xlhs, M) && dalloc(h, &W.ilhs, M) && dalloc(h, &W.xval, M) &&
+             dalloc(h, &W.out, 4) && dalloc(h, &W.lt_ptr, M + 1) && dalloc(h, &W.lt_cur, M);
+    a = a && hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset") &&
+        hip_ok(h, hipMemset(W.work, 0, M * sizeof(double)), "hipMemset") &&
+        hip_ok(h, hipMemset(W.xlhs, 0, M * sizeof(double)), "hipMemset");
+    if (!a) return BLU_ERROR_OUT_OF_MEMORY;
+    h->sw_ready = true;
+    h->marker = 0;
+    return BLU_OK;
+}
+// row-wise L of THIS factorization (build_factors.rs:243-274), built on the device at the first solve that needs it
+static int ensure_lt(blu_hip *h)
+{
+    const int st = ensure_sparse_ws(h);
+    if (st != BLU_OK) return st;
+    if (h->lt_for_nfact == h->nfactorize) return BLU_OK;
+    SparseWs &W = h->sw;
+    const int64_t lnz = std::max<int64_t>((int64_t)h->hs.lused, 1);
+    if (lnz > h->sw_ltcap) {
+        dfree(W.lt_idx);
+        dfree(W.lt_val);
+        if (!dalloc(h, &W.lt_idx, (size_t)lnz) || !dalloc(h, &W.lt_val, (size_t)lnz)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->sw_ltcap = lnz;
+    }
+    hipLaunchKernelGGL(k_build_lt, dim3(1), dim3(1024), 0, h->stream, h->dD, W);
+    if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_build_lt")) return BLU_ERROR_DEVICE;
+    h->lt_for_nfact = h->nfactorize;
+    return BLU_OK;
+}
+
 // BLU::solve_dense -- src/blu.rs:182, lu/solve_dense.rs:7-120 (fresh factorization: nforrest == 0)
 extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, char trans)
 {
@@ -501,7 +538,12 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     const size_t M = (size_t)h->m;
     if (!hip_ok(h, hipMemcpy(h->d_rhs, rhs, M * 8, hipMemcpyHostToDevice), "h2d rhs")) return BLU_ERROR_DEVICE;
     const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
-    hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO, h->d_rhs, h->d_lhs, tr);
+    if (!tr) { // the forward L solve takes row dots (solve_dense.rs:79-86)
+        const int st = ensure_lt(h);
+        if (st != BLU_OK) return st;
+    }
+    hipLaunchKernelGGL(k_solve_dense, dim3(1), dim3(1024), 0, h->stream, h->dD, h->dO, h->d_rhs, h->d_lhs, tr, h->sw.lt_ptr, h->sw.lt_idx,
+                       h->sw.lt_val);
     if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_dense")) return BLU_ERROR_DEVICE;
     if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
     return BLU_OK;
@@ -523,33 +565,18 @@ extern "C" int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *i
     if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
     const size_t M = (size_t)h->m;
     SparseWs &W = h->sw;
-    if (!h->sw_ready) {
-        bool a = dalloc(h, &W.marked, M) && dalloc(h, &W.psym, M) && dalloc(h, &W.pat, M) && dalloc(h, &W.pstack, M) &&
-                 dalloc(h, &W.work, M) && dalloc(h, &W.xlhs, M) && dalloc(h, &W.ilhs, M) && dalloc(h, &W.xval, M) &&
-                 dalloc(h, &W.out, 4) && dalloc(h, &W.lt_ptr, M + 1) && dalloc(h, &W.lt_cur, M);
-        a = a && hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset") &&
-            hip_ok(h, hipMemset(W.work, 0, M * sizeof(double)), "hipMemset") &&
-            hip_ok(h, hipMemset(W.xlhs, 0, M * sizeof(double)), "hipMemset");
-        if (!a) return BLU_ERROR_OUT_OF_MEMORY;
-        h->sw_ready = true;
-        h->marker = 0;
+    {
+        const int st = ensure_sparse_ws(h);
+        if (st != BLU_OK) return st;
     }
     if (h->marker > 0x7fffffff - 8) { // lu.rs:301-305: reset the marks before the marker overflows
         if (!hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset")) return BLU_ERROR_DEVICE;
         h->marker = 0;
     }
     const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
-    if (tr && h->lt_for_nfact != h->nfactorize) { // row-wise L of THIS factorization
-        const int64_t lnz = std::max<int64_t>((int64_t)h->hs.lused, 1);
-        if (lnz > h->sw_ltcap) {
-            dfree(W.lt_idx);
-            dfree(W.lt_val);
-            if (!dalloc(h, &W.lt_idx, (size_t)lnz) || !dalloc(h, &W.lt_val, (size_t)lnz)) return BLU_ERROR_OUT_OF_MEMORY;
-            h->sw_ltcap = lnz;
-        }
-        hipLaunchKernelGGL(k_build_lt, dim3(1), dim3(1024), 0, h->stream, h->dD, W);
-        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_build_lt")) return BLU_ERROR_DEVICE;
-        h->lt_for_nfact = h->nfactorize;
+    if (tr) { // the transposed system ends with L': row-wise L
+        const int st = ensure_lt(h);
+        if (st != BLU_OK) return st;
     }
     if (nzrhs > h->rhs_cap) {
         dfree(h->d_irhs);

@@ -15,184 +15,7 @@
 // +-1 right-hand-side choices (`temp >= 0`, `d <= 0`) are made on identically defined quantities.
 #include "blu_dev.h"
 
-typedef GPTR(const long long) gcll_p;
-typedef GPTR(const double) gcdouble_p;
-
-// ------------------------------------------------------------------------------------------------
-// Pipelined triangular sweeps.  A sweep is a chain of m dependent steps: step k reads entries of the
-// work vector that step k-1 may just have written.  What does NOT depend on the previous step -- the
-// column pointers, the column's (index, value) entries, its diagonal / pivot row -- is fetched one and
-// two steps ahead, so that a step costs ONE memory round trip (the gather of the work vector) instead
-// of four.  Lanes hold one entry each of the first 64 of a column; longer columns (rare) take the slow
-// tail loops.  One lane's store to the work vector is seen by the other lanes' later loads without a
-// drain: a wave's memory operations are performed in order (wave_mem_sync = wavefront-scope fence).
-// ------------------------------------------------------------------------------------------------
-struct ColPtr {
-    long long b, e; // entries [b, e)
-    double diag;    // U: pivot (last entry of the column); unused for L
-    int aux;        // stage L: prow[k]
-};
-struct ColEnt {
-    int idx;
-    double val;
-};
-// U columns of the canonical factors: off-diagonals [colptr[k], colptr[k+1]-1), pivot last
-struct UCols {
-    gcll_p colptr, rowidx;
-    gcdouble_p value;
-    int m;
-    __device__ __forceinline__ ColPtr ptr(int k) const
-    {
-        ColPtr P;
-        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = colptr[k];
-        P.e = colptr[k + 1] - 1;
-        P.diag = 0.0;
-        P.aux = 0;
-        return P;
-    }
-    __device__ __forceinline__ void diag(ColPtr &P) const { P.diag = value[P.e]; }
-    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
-    {
-        ColEnt E;
-        E.idx = 0;
-        E.val = 0.0;
-        const long long p = P.b + off + lane_id();
-        if (p < P.e) {
-            E.idx = (int)rowidx[p];
-            E.val = value[p];
-        }
-        return E;
-    }
-};
-// sorted L columns of the canonical factors without the unit diagonal: (colptr[k], colptr[k+1])
-struct LCols {
-    gcll_p colptr, rowidx;
-    gcdouble_p value;
-    int m;
-    __device__ __forceinline__ ColPtr ptr(int k) const
-    {
-        ColPtr P;
-        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = colptr[k] + 1;
-        P.e = colptr[k + 1];
-        P.diag = 1.0;
-        P.aux = 0;
-        return P;
-    }
-    __device__ __forceinline__ void diag(ColPtr &) const {}
-    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
-    {
-        ColEnt E;
-        E.idx = 0;
-        E.val = 0.0;
-        const long long p = P.b + off + lane_id();
-        if (p < P.e) {
-            E.idx = (int)rowidx[p];
-            E.val = value[p];
-        }
-        return E;
-    }
-};
-// stage-ordered L columns as the pivot loop wrote them (row indices of B): the reference's own storage
-// and summation order (l_begin_p, pivot.rs:404-416); `map` (or null) takes a row index to its position
-struct LStage {
-    gcint_p lbeg, lidx, prow, map;
-    gcdouble_p lval;
-    int m;
-    __device__ __forceinline__ ColPtr ptr(int k) const
-    {
-        ColPtr P;
-        k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = lbeg[k];
-        P.e = lbeg[k + 1];
-        P.diag = 1.0;
-        P.aux = prow[k];
-        return P;
-    }
-    __device__ __forceinline__ void diag(ColPtr &) const {}
-    __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
-    {
-        ColEnt E;
-        E.idx = 0;
-        E.val = 0.0;
-        const long long p = P.b + off + lane_id();
-        if (p < P.e) {
-            const int i = lidx[p];
-            E.idx = map ? map[i] : i;
-            E.val = lval[p];
-        }
-        return E;
-    }
-};
-
-// sum of prod over lanes 0..n-1 in lane order, every lane gets it (the reference's sequential loop)
-__device__ __forceinline__ double wave_ordered_sum(double prod, int n, double acc)
-{
-    const unsigned lo = (unsigned)__double_as_longlong(prod), hi = (unsigned)(__double_as_longlong(prod) >> 32);
-    for (int t = 0; t < n; t++) {
-        const unsigned a = __builtin_amdgcn_readlane(lo, t), b = __builtin_amdgcn_readlane(hi, t);
-        acc = __dadd_rn(acc, __longlong_as_double((long long)(((unsigned long long)b << 32) | a)));
-    }
-    return acc;
-}
-
-// ordered dot of column P with the work vector x (first chunk E already in registers)
-template <class Cols>
-__device__ __forceinline__ double col_dot(const Cols &C, const ColPtr &P, const ColEnt &E, gdouble_p x)
-{
-    const long long len = P.e - P.b;
-    if (len <= 0) return 0.0;
-    const int lane = lane_id();
-    const int n0 = len < 64 ? (int)len : 64;
-    double acc = wave_ordered_sum(lane < n0 ? __dmul_rn(x[E.idx], E.val) : 0.0, n0, 0.0);
-    for (long long off = 64; off < len; off += 64) {
-        const ColEnt E2 = C.ent(P, off);
-        const int n = (len - off) < 64 ? (int)(len - off) : 64;
-        acc = wave_ordered_sum(lane < n ? __dmul_rn(x[E2.idx], E2.val) : 0.0, n, acc);
-    }
-    return acc;
-}
-// x[idx] = x[idx] -/+ t * val over column P (sub: minus)
-template <bool SUB, class Cols>
-__device__ __forceinline__ void col_scatter(const Cols &C, const ColPtr &P, const ColEnt &E, gdouble_p x, double t)
-{
-    const long long len = P.e - P.b;
-    const int lane = lane_id();
-    if (lane < len) {
-        const double pr = __dmul_rn(t, E.val);
-        x[E.idx] = SUB ? __dsub_rn(x[E.idx], pr) : __dadd_rn(x[E.idx], pr);
-    }
-    for (long long off = 64; off < len; off += 64) {
-        const ColEnt E2 = C.ent(P, off);
-        if (off + lane < len) {
-            const double pr = __dmul_rn(t, E2.val);
-            x[E2.idx] = SUB ? __dsub_rn(x[E2.idx], pr) : __dadd_rn(x[E2.idx], pr);
-        }
-    }
-}
-
-// for k = k0, k0+dir, .. (n steps): body(k, P_k, E_k) with the pointers of step k+2 and the entries of
-// step k+1 in flight
-template <class Cols, class Body>
-__device__ __forceinline__ void sweep(const Cols &C, int k0, int dir, int n, Body body)
-{
-    if (n <= 0) return;
-    ColPtr P1 = C.ptr(k0);
-    C.diag(P1);
-    ColEnt E1 = C.ent(P1, 0);
-    ColPtr P2 = C.ptr(k0 + dir);
-    for (int s = 0, k = k0; s < n; s++, k += dir) {
-        C.diag(P2);
-        const ColEnt E2 = C.ent(P2, 0);
-        const ColPtr P3 = C.ptr(k + 2 * dir);
-        body(k, P1, E1);
-        wave_mem_sync();
-        P1 = P2;
-        E1 = E2;
-        P2 = P3;
-    }
-}
+#include "k_sweep.h"
 
 __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
 {

@@ -437,3 +437,22 @@ def test_solve_sparse_golden_fixtures(blu):
             assert h.solve_sparse(g[key + "_irhs"], g[key + "_xrhs"], chr(int(g[key + "_trans"]))) == K.OK
             il = h.ilhs[:h.nzlhs]
             assert np.array_equal(il, g[key + "_ilhs"]) and np.array_equal(h.lhs[il], g[key + "_xlhs"]), key
+
+
+@pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1500, 8, 16, 0.2, 3, 1.0)], ids=lambda s: "m%d" % s[0])
+def test_solve_dense_identical_to_oracle(blu, oracle, spec):
+    """solve_dense keeps the reference's operation order (solve_dense.rs:32-119): bit-identical results,
+    both systems, full-rank and rank-deficient factors."""
+    cp, ri, v = oracle.gen_lp_basis(*spec)
+    m = spec[0]
+    rng = np.random.default_rng(5)
+    for singular in (False, True):
+        vv = v.copy()
+        if singular:
+            for j in (3, m // 3, m - 1):
+                vv[int(cp[j]):int(cp[j + 1])] *= 1e-17
+        g, o, sg, so = _both(blu, oracle, cp, ri, vv, fix_d3=True)
+        assert sg == so == (K.WARNING_SINGULAR_MATRIX if singular else K.OK)
+        for trans in "NT":
+            b = rng.standard_normal(m)
+            assert np.array_equal(g.solve_dense(b, trans), o.solve_dense(b, trans)), (singular, trans)
