@@ -9,10 +9,11 @@
 // factors k_finish wrote (O: L unit lower CSC diagonal first, U upper CSC pivot last), i.e. on
 //   B[rowperm, colperm] = L * U,  vector index k <-> row rowperm[k] / column colperm[k].
 //
-// Floating point: dots are accumulated by ONE lane in storage order (the reference's loop order for the
-// U sweeps and the forward L sweep; the L dots of condest/backward use the sorted column instead of the
-// stage order), so values agree with the reference to rounding (tested at 1e-9 relative), and the
-// +-1 right-hand-side choices (`temp >= 0`, `d <= 0`) are made on identically defined quantities.
+// Floating point: every sum is taken in the reference's order -- dots over a line in its storage order
+// (lane order of wave_ordered_sum), scatter updates of one entry in ascending pivot order, the residual
+// terms of a row ascending in the pivot position of their columns, the 1-norms sequentially over the row
+// indices -- so all statistics, including residual_test (pure rounding noise), are bit-identical to it
+// (tests: test_statistics_tail*).
 #include "blu_dev.h"
 
 #include "k_sweep.h"
@@ -131,8 +132,8 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
     // ---- norms of L and U (condest.rs:27-44), 1-norm = max column sum
     double nl = 0.0, nu = 0.0;
     for (int k = tid; k < m; k += nt) {
-        double s = 1.0;
-        for (long long p = O.l_colptr[k] + 1; p < O.l_colptr[k + 1]; p++) s += fabs(O.l_value[p]);
+        double s = 1.0; // (stage-ordered column: the reference's storage and summation order)
+        for (int p = D.lbeg[k]; p < D.lbeg[k + 1]; p++) s += fabs(D.lval[p]);
         nl = fmax(nl, s);
         const long long e = O.u_colptr[k + 1] - 1;
         double t = fabs(O.u_value[e]);
@@ -160,16 +161,39 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
             rb[k] = rb[k] - lb[k];
         }
     }
-    // forward residual rhs - B*lhs and row sums: one thread per ROW of B (bt_* = B row-wise, sorted by column)
+    // forward residual rhs - B*lhs and row sums: one thread per ROW of B (bt_* = B row-wise).  The
+    // reference scatters column after column in pivot order (residual_test.rs:68-76, matrix_norm.rs:
+    // 26-36), so a row receives its terms ascending in the pivot position of their columns: the entries
+    // of the row are taken in that order (selection by repeated minimum; rows are short).
     for (int i = tid; i < m; i += nt) {
         const int kr = D.pinv[i];
         double acc = rf[kr], rsum = 0.0;
-        for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) {
-            const int kc = D.qinv[D.bt_idx[p]];
-            if (kc < rank) {
-                const double a = D.bt_val[p];
-                acc = __dsub_rn(acc, __dmul_rn(lf[kc], a));
+        const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
+        if (e - b <= 256) {
+            int last = -1;
+            for (int t = b; t < e; t++) {
+                int best = 0x7fffffff, bp = -1;
+                for (int p = b; p < e; p++) {
+                    const int kc = D.qinv[D.bt_idx[p]];
+                    if (kc > last && kc < best) {
+                        best = kc;
+                        bp = p;
+                    }
+                }
+                if (bp < 0 || best >= rank) break;
+                const double a = D.bt_val[bp];
+                acc = __dsub_rn(acc, __dmul_rn(lf[best], a));
                 rsum += fabs(a);
+                last = best;
+            }
+        } else { // a very long row: storage order (the sums then agree with the reference to rounding only)
+            for (int p = b; p < e; p++) {
+                const int kc = D.qinv[D.bt_idx[p]];
+                if (kc < rank) {
+                    const double a = D.bt_val[p];
+                    acc = __dsub_rn(acc, __dmul_rn(lf[kc], a));
+                    rsum += fabs(a);
+                }
             }
         }
         if (kr >= rank) {
@@ -180,24 +204,26 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
         rs[i] = rsum;
     }
     __syncthreads();
-    double s_lf = 0.0, s_rf = 0.0, s_lb = 0.0, s_rb = 0.0, inf = 0.0;
-    for (int k = tid; k < m; k += nt) {
-        s_lf += fabs(lf[k]);
-        s_rf += fabs(rf[k]);
-        s_lb += fabs(lb[k]);
-        s_rb += fabs(rb[k]);
-        inf = fmax(inf, rs[k]);
-    }
-    // workgroup reductions: sums and maxima
-    double vals[8] = {s_lf, s_rf, s_lb, s_rb, nl, nu, one, inf};
-    for (int q = 0; q < 8; q++) {
-        double v = vals[q];
-        if (q < 4) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        } else {
-            v = wave_max_d(v);
+    // the four 1-norms (residual_test.rs:7-13: a sequential sum over the ROW indices 0..m-1): one wave
+    // each, 64 terms fetched together and added in lane order
+    for (int q = 0; q < 4; q++) {
+        if (w != (nw >= 4 ? q : 0)) continue;
+        gdouble_p vec = q == 0 ? lf : (q == 1 ? rf : (q == 2 ? lb : rb));
+        double s = 0.0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const int n = m - i0 < 64 ? m - i0 : 64;
+            s = wave_ordered_sum(i < m ? fabs(vec[D.pinv[i]]) : 0.0, n, s);
         }
+        if (lane == 0) chain_out[4 + q] = s;
+    }
+    double inf = 0.0;
+    for (int k = tid; k < m; k += nt) inf = fmax(inf, rs[k]);
+    // workgroup reductions: maxima
+    double vals[8] = {0.0, 0.0, 0.0, 0.0, nl, nu, one, inf};
+    for (int q = 4; q < 8; q++) {
+        double v = vals[q];
+        v = wave_max_d(v);
         if (lane == 0) red[q & 3][w] = v;
         __syncthreads();
         if (tid == 0) {
