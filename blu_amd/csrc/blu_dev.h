@@ -94,17 +94,22 @@ struct Scalars {
 //   gwork          16 * (m+1) doubles: pivot_any dense work columns
 //   iw0,iw1        m+2 ints each: prep / finish scratch
 //   lbeg..uval     factors in stage order: L column k = lidx/lval[lbeg[k]..lbeg[k+1]), U row k likewise
-#define DEVLU_ARRAYS(X)                                                                                \
-    X(const unsigned long long, b_begin) X(const unsigned long long, b_end) X(const unsigned long long, b_i) \
-    X(const double, b_x)                                                                               \
-    X(int, bc_ptr) X(int, bc_idx) X(double, bc_val) X(int, bt_ptr) X(int, bt_idx) X(double, bt_val)    \
+// HOT = what the low-latency paths of the pivot loop touch at every pivot; COLD = inputs, the packed
+// copies of B, and the scratch of the general pivot paths (see DevGP below).
+#define DEVLU_ARRAYS_HOT(X)                                                                            \
     X(int, pinv) X(int, qinv) X(int, prow) X(int, pcol)                                                \
     X(int, cbeg) X(int, clen) X(int, ccap) X(int, cidx) X(double, cval)                                \
     X(int, rbeg) X(int, rlen) X(int, rcap) X(int, ridx) X(double, colmax)                              \
-    X(int, cflink) X(int, cblink) X(int, rflink) X(int, rblink)                                        \
-    X(int, rowmark) X(int, colmark) X(int, tnew) X(int, tnewr) X(double, txrj)                         \
-    X(unsigned long long, tmask) X(double, gwork) X(int, iw0) X(int, iw1) X(int, iw2)                  \
+    X(int, cflink) X(int, cblink)                                                                      \
     X(int, lbeg) X(int, ubeg) X(int, lidx) X(int, uidx) X(double, lval) X(double, uval)
+#define DEVLU_ARRAYS_COLD(X)                                                                           \
+    X(const unsigned long long, b_begin) X(const unsigned long long, b_end) X(const unsigned long long, b_i) \
+    X(const double, b_x)                                                                               \
+    X(int, bc_ptr) X(int, bc_idx) X(double, bc_val) X(int, bt_ptr) X(int, bt_idx) X(double, bt_val)    \
+    X(int, rflink) X(int, rblink)                                                                      \
+    X(int, rowmark) X(int, colmark) X(int, tnew) X(int, tnewr) X(double, txrj)                         \
+    X(unsigned long long, tmask) X(double, gwork) X(int, iw0) X(int, iw1) X(int, iw2)
+#define DEVLU_ARRAYS(X) DEVLU_ARRAYS_HOT(X) DEVLU_ARRAYS_COLD(X)
 
 // The descriptor as the host fills it and as it lives in HBM: plain (generic) pointers.
 struct DevLU {
@@ -151,6 +156,45 @@ struct DevG {
               DEVLU_ARRAYS(X)
 #undef X
                   s(d.s)
+    {
+    }
+};
+
+// View for the pivot loop.  The kernel keeps its base pointers in scalar registers; with all ~40 of them
+// live the allocator spills SGPRs into VGPR lanes and reloads them (v_readlane) all over the hot path.
+// The COLD arrays -- touched only by the general pivot paths, or not at all in this kernel -- are
+// therefore not held: a ColdArr fetches its pointer from the descriptor (one scalar load) where it is used.
+template <class T> struct ColdArr {
+    GPTR(T *const) slot; // where the pointer sits inside the descriptor (global memory)
+    __device__ __forceinline__ GPTR(T) get() const { return (GPTR(T))(*slot); }
+    __device__ __forceinline__ operator GPTR(T)() const { return get(); }
+    __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](int i) const { return get()[i]; }
+    __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](size_t i) const { return get()[i]; }
+    __device__ __forceinline__ GPTR(T) operator+(int i) const { return get() + i; }
+};
+struct DevGP {
+#define X(T, n) T n;
+    DEVLU_SCALARS(X)
+#undef X
+#define X(T, n) GPTR(T) n;
+    DEVLU_ARRAYS_HOT(X)
+#undef X
+#define X(T, n) ColdArr<T> n;
+    DEVLU_ARRAYS_COLD(X)
+#undef X
+    Scalars *s;
+    __device__ __forceinline__ explicit DevGP(const DevLU *d)
+        :
+#define X(T, n) n(d->n),
+          DEVLU_SCALARS(X)
+#undef X
+#define X(T, n) n((GPTR(T))d->n),
+              DEVLU_ARRAYS_HOT(X)
+#undef X
+#define X(T, n) n{(GPTR(T *const)) & d->n},
+                  DEVLU_ARRAYS_COLD(X)
+#undef X
+                      s(d->s)
     {
     }
 };

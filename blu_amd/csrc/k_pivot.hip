@@ -70,7 +70,11 @@ struct alignas(16) Sm {
     struct alignas(16) {
         int nzc, nzr, pcb, prb;
     };
+#ifdef BLU_PROFILE
     long long prof[48];
+#else
+    long long prof[1];
+#endif
     int rank, rankdef, min_colnz, min_rownz;
     int cused, rused, lused, uused;
     int need;
@@ -193,7 +197,7 @@ __device__ __forceinline__ int wave_find(gcint_p idx, int beg, int len, int key)
 // 15 % SLOWER -- the calls force the ~50 descriptor pointers and the live state through scratch
 // (156 scratch_load in the loop) -- so the instruction-cache footprint is the lesser evil.
 #define COLD __forceinline__
-__device__ COLD void markowitz_wave(const DevG &D, Sm *sm)
+__device__ COLD void markowitz_wave(const DevGP &D, Sm *sm)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -280,7 +284,7 @@ __device__ COLD void markowitz_wave(const DevG &D, Sm *sm)
 
 // Markowitz search with row search enabled (search_rows != 0): verbatim single-lane restatement of
 // markowitz.rs:34-193.  Not the default; kept simple.
-__device__ COLD void markowitz_serial(const DevG &D, Sm *sm)
+__device__ COLD void markowitz_serial(const DevGP &D, Sm *sm)
 {
     const int m = D.m;
     Scalars *S = D.s;
@@ -395,7 +399,7 @@ __device__ COLD void markowitz_serial(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // remove_col (pivot.rs:1333-1381): verbatim, one lane (rare: a column maximum fell below abstol)
 // ------------------------------------------------------------------------------------------------
-__device__ COLD void remove_col_serial(const DevG &D, Sm *sm, int j)
+__device__ COLD void remove_col_serial(const DevGP &D, Sm *sm, int j)
 {
     const int m = D.m;
     const int cbeg = D.cbeg[j], cend = cbeg + D.clen[j];
@@ -423,7 +427,7 @@ __device__ COLD void remove_col_serial(const DevG &D, Sm *sm, int j)
 // pivot_any / pivot_small: one target column per wave (pivot.rs:219-331 / :566-691)
 // q = position of the column in the pivot row (>= 1), work = this wave's dense work column
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gen_update_col(const DevG &D, Sm *sm, int q, bool small, double *work)
+__device__ __forceinline__ void gen_update_col(const DevGP &D, Sm *sm, int q, bool small, double *work)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -568,7 +572,7 @@ __device__ __forceinline__ void gen_update_col(const DevG &D, Sm *sm, int q, boo
 }
 
 // one target row per wave (pivot.rs:335-398 / :704-771); p = position in the pivot column (>= 1)
-__device__ __forceinline__ void gen_update_row(const DevG &D, Sm *sm, int p, bool small)
+__device__ __forceinline__ void gen_update_row(const DevGP &D, Sm *sm, int p, bool small)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -631,7 +635,7 @@ __device__ __forceinline__ void gen_update_row(const DevG &D, Sm *sm, int p, boo
 
 // U row of this stage: pivot-row entries with |xrj| > droptol in pivot-row order (pivot.rs:306-312),
 // ONE wave.  elems = pivot row line, positions q0..q1 (inclusive), txrj[q] = value, skipq = position to skip.
-__device__ __forceinline__ void wave_write_u(const DevG &D, Sm *sm, int q0, int q1, int skipq)
+__device__ __forceinline__ void wave_write_u(const DevGP &D, Sm *sm, int q0, int q1, int skipq)
 {
     const int lane = lane_id();
     int put = sm->uused;
@@ -656,7 +660,7 @@ __device__ __forceinline__ void wave_write_u(const DevG &D, Sm *sm, int q0, int 
 
 // L column of this stage: x = val / pivot for the pivot-column entries p0..p1 except skipp, kept if
 // |x| > droptol (pivot.rs:404-416).  ONE wave.
-__device__ __forceinline__ void wave_write_l(const DevG &D, Sm *sm, int p0, int p1, int skipp)
+__device__ __forceinline__ void wave_write_l(const DevGP &D, Sm *sm, int p0, int p1, int skipp)
 {
     const int lane = lane_id();
     int put = sm->lused;
@@ -683,7 +687,7 @@ __device__ __forceinline__ void wave_write_l(const DevG &D, Sm *sm, int p0, int 
 // ------------------------------------------------------------------------------------------------
 // pivot_any / pivot_small, whole workgroup.  Returns false if the kernel must exit (NEED_*).
 // ------------------------------------------------------------------------------------------------
-__device__ COLD bool pivot_general(const DevG &D, Sm *sm, bool small)
+__device__ COLD bool pivot_general(const DevGP &D, Sm *sm, bool small)
 {
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -795,7 +799,7 @@ __device__ COLD bool pivot_general(const DevG &D, Sm *sm, bool small)
 // ------------------------------------------------------------------------------------------------
 // pivot_singleton_row (pivot.rs:835-926)
 // ------------------------------------------------------------------------------------------------
-__device__ COLD bool pivot_singleton_row(const DevG &D, Sm *sm)
+__device__ COLD bool pivot_singleton_row(const DevGP &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -855,7 +859,7 @@ __device__ COLD bool pivot_singleton_row(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // pivot_singleton_col (pivot.rs:928-1025)
 // ------------------------------------------------------------------------------------------------
-__device__ COLD bool pivot_singleton_col(const DevG &D, Sm *sm)
+__device__ COLD bool pivot_singleton_col(const DevGP &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -933,7 +937,7 @@ __device__ COLD bool pivot_singleton_col(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // pivot_doubleton_col (pivot.rs:1027-1331)
 // ------------------------------------------------------------------------------------------------
-__device__ COLD bool pivot_doubleton_col(const DevG &D, Sm *sm)
+__device__ COLD bool pivot_doubleton_col(const DevGP &D, Sm *sm)
 {
     const int tid = threadIdx.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1164,7 +1168,7 @@ __device__ COLD bool pivot_doubleton_col(const DevG &D, Sm *sm)
 
 // set-up of a pivot for the general paths (after the general searches, or for a pivot that was
 // pending when the kernel left with NEED_*): line positions and the L/U room check of pivot.rs:70-81
-__device__ COLD void setup_pivot_general(const DevG &D, Sm *sm)
+__device__ COLD void setup_pivot_general(const DevGP &D, Sm *sm)
 {
     Scalars *S = D.s;
     const int pr = sm->pr, pc = sm->pc;
@@ -1189,7 +1193,7 @@ __device__ COLD void setup_pivot_general(const DevG &D, Sm *sm)
 
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
-    const DevG D(Ds[blockIdx.x]);
+    const DevGP D(&Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ Sm smem;
     Sm *sm = &smem;
@@ -1219,7 +1223,9 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->fa.ewFlag = 0;
         sm->fa.ewValid = 0;
         for (int k = 0; k < 12; k++) sm->kinds[k] = 0;
+#ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) sm->prof[k] = 0;
+#endif
     }
     for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
     for (int k = tid; k < 2 * KGMAX; k += blockDim.x) sm->fa.kg[0][k] = 0ull;

@@ -125,7 +125,7 @@ struct InHRow {
 // column / pivot row, list.rs:81-86 at the end of every pivot path).
 template <class InSet>
 __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
-                                        InSet inS, int big, int gone, int *scratch /* 320 ints of LDS */,
+                                        InSet inS, int big, int gone,
                                         unsigned long long *kg /* KGMAX words of LDS, all zero between calls */,
                                         Fast *pub /* or null: publish the unlinked runs for early_search */, int seq = 0)
 {
@@ -304,7 +304,7 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
 //             LDS, hash sets, room checks, fa->kind
 // mk_walk returns: 0 candidates found, 1 empty column chosen (pr = -1), 2 error, 3 shape not handled
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
+__device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -381,7 +381,7 @@ __device__ __forceinline__ int mk_walk(const DevG &D, Sm *sm)
     return 0;
 }
 
-__device__ __forceinline__ void mk_stage(const DevG &D, Sm *sm, long long &mcb, int &fb)
+__device__ __forceinline__ void mk_stage(const DevGP &D, Sm *sm, long long &mcb, int &fb)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -435,7 +435,7 @@ __device__ __forceinline__ void mk_stage(const DevG &D, Sm *sm, long long &mcb, 
 // staged: 4 dependent loads (list heads, column, entry, row) instead of 6, and no reduction.
 // Returns false (nothing modified) if the count-1 list is empty or anything is unusual; the caller
 // then takes the ordinary route, which also raises the errors.
-__device__ __forceinline__ bool mk_express(const DevG &D, Sm *sm, int &nsearched)
+__device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, int &nsearched)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -474,7 +474,7 @@ __device__ __forceinline__ bool mk_express(const DevG &D, Sm *sm, int &nsearched
     return true;
 }
 
-__device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, int fb, int nsearched)
+__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, int fb, int nsearched)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -598,7 +598,7 @@ __device__ __forceinline__ void mk_pick(const DevG &D, Sm *sm, long long mcb, in
 
 // the complete search on the current list state.  Returns false if the shape is outside what this path
 // handles (nothing has been modified then; the caller runs the general search).
-__device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
+__device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm)
 {
     Fast *fa = &sm->fa;
     if (lane_id() == 0) fa->kind = 0;
@@ -670,7 +670,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevG &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // idx_first/val_first: this lane's entry of the first 64-entry chunk, loaded by the caller ahead of
 // time (the caller issues the loads of all its tasks before processing any of them)
-__device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *work, int idx_first, double val_first, int pr, int cnz1,
+__device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *work, int idx_first, double val_first, int pr, int cnz1,
                                          double pivot)
 {
     const int lane = lane_id();
@@ -787,8 +787,10 @@ __device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *w
         D.ccap[j] = newcap;
         D.colmax[j] = cmx;
         fa->tNew[q] = newlen;
-        fa->tB[q] = dst;  // (new begin and maximum: the early search of the next pivot reads them)
-        fa->tMx[q] = cmx;
+        if (BLU_EARLY) { // new begin and maximum: the early search of the next pivot reads them
+            fa->tB[q] = dst;
+            fa->tMx[q] = cmx;
+        }
         fa->tX[q] = xrj;
         fa->tM[q] = mask;
         if (mask) fa->anycancel = 1;
@@ -800,7 +802,7 @@ __device__ __forceinline__ void fast_col(const DevG &D, Sm *sm, int q, double *w
 
 // kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
 // cancelled by fast_col are removed afterwards by fast_fixrow.
-__device__ __forceinline__ void fast_row(const DevG &D, Sm *sm, int p, int j_first, int pc, int rnz1)
+__device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, int p, int j_first, int pc, int rnz1)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -862,7 +864,7 @@ __device__ __forceinline__ void fast_row(const DevG &D, Sm *sm, int p, int j_fir
 }
 
 // rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
-__device__ __forceinline__ void fast_fixrow(const DevG &D, Sm *sm, int p)
+__device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, int p)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -894,7 +896,7 @@ __device__ __forceinline__ int wave_min_key(const int *keys, int n, int big)
 }
 
 // U row from the LDS copies (pivot.rs:306-312): slots q0..q1 of the pivot row except skipq
-__device__ __forceinline__ void fast_write_u(const DevG &D, Sm *sm, int q0, int q1, int skipq)
+__device__ __forceinline__ void fast_write_u(const DevGP &D, Sm *sm, int q0, int q1, int skipq)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -919,7 +921,7 @@ __device__ __forceinline__ void fast_write_u(const DevG &D, Sm *sm, int q0, int 
 }
 
 // L column from the LDS copy (pivot.rs:404-416): slots 1..cnz1
-__device__ __forceinline__ void fast_write_l(const DevG &D, Sm *sm)
+__device__ __forceinline__ void fast_write_l(const DevGP &D, Sm *sm)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -963,7 +965,7 @@ __device__ __forceinline__ void fast_write_l(const DevG &D, Sm *sm)
 // fix-up is pending, row search is on, the batch took the long path, fewer than 4 waves.
 // `make ewcheck` compares every early result with the ordinary search.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void early_search(const DevG &D, Sm *sm, const int *elems, const int *keys, const int *begs, const double *maxs,
+__device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *elems, const int *keys, const int *begs, const double *maxs,
                                              int n)
 {
     const int lane = lane_id();
@@ -1021,7 +1023,7 @@ __device__ __forceinline__ void early_search(const DevG &D, Sm *sm, const int *e
     const int np = fa->ewNP;
     const int myP = lane < np ? fa->ewP[lane] : -1, myF = lane < np ? fa->ewF[lane] : 0;
     if (amb) { // heads whose first member was moved
-        int *win = fa->ls[1]; // 64 ints (scratch of the row-list batch: row search is off here)
+        int *win = fa->ewWin;
         win[lane] = -2;
         wave_mem_sync();
         if (myP >= m + nz && myP < m + nz + 64) win[myP - m - nz] = myF;
@@ -1155,7 +1157,7 @@ __device__ __forceinline__ void early_search(const DevG &D, Sm *sm, const int *e
 // ------------------------------------------------------------------------------------------------
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc, int nzc, int nzr)
+__device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int pc, int nzc, int nzr)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
     }
     if (w == 2 % nw) {
         PROF_STAMP_L0(25);
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->ls[0], fa->kg[0],
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->kg[0],
                                                 early ? fa : nullptr, sm->rank + 1);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
         PROF_WAIT();
@@ -1264,7 +1266,7 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
     if (D.search_rows && w == 3 % nw) {
         if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->ls[1], fa->kg[1],
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->kg[1],
                                                 (Fast *)nullptr);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
@@ -1274,7 +1276,7 @@ __device__ __forceinline__ void fast_small(const DevG &D, Sm *sm, int pr, int pc
 // ------------------------------------------------------------------------------------------------
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc, int rl, int wq)
+__device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc, int rl, int wq)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1314,7 +1316,7 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc,
             D.clen[j] = cl - 1;
             D.colmax[j] = cmx;
             fa->tNew[q] = cl - 1;
-            fa->tMx[q] = cmx;
+            if (BLU_EARLY) fa->tMx[q] = cmx;
             fa->tX[q] = xrj;
             if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
         }
@@ -1336,7 +1338,7 @@ __device__ __forceinline__ void fast_scol(const DevG &D, Sm *sm, int pr, int pc,
     if (w == 1 % nw) {
         if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
         // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->ls[0], fa->kg[0],
+        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->kg[0],
                                                 early ? fa : nullptr, sm->rank + 1);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
     }

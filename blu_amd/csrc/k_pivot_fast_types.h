@@ -6,7 +6,7 @@
 #define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
 #define HROW 256    // hash slots, rows of the pivot column (<= 64 keys)
 #define HCOL 512    // hash slots, columns of the pivot row (<= 256 keys)
-#define KGMAX 256    // batched list moves: keys (new counts) below this meet in an LDS table
+#define KGMAX 128    // batched list moves: keys (new counts) below this meet in an LDS table
 #define HROW_BITS 8
 #define HCOL_BITS 9
 // Early search (early_search in k_pivot_fast.hip): wave 0 finds and stages the candidates of pivot k+1
@@ -30,21 +30,27 @@ struct Fast {
     // and the result kept for the next search
     int ewFlag, ewNP, ewValid, ewNsr;
     unsigned long long ewMask;
-    int ewP[64], ewF[64], ewFb[64];
+#if BLU_EARLY
+    int ewP[64], ewF[64], ewFb[64], ewWin[64];
     long long ewMcb[64];
+    double tMx[PRMAX]; // new maximum of every column of the pivot row
+#else
+    int ewP[1], ewF[1], ewFb[1], ewWin[1]; // (the early search is compiled out: no LDS for it)
+    long long ewMcb[1];
+    double tMx[1];
+#endif
     // pivot column, pivot at slot 0 (kind 1), with the (begin,len,cap) of each row
     int pcI[PCMAX], prB[PCMAX], prL[PCMAX], prC[PCMAX], rNew[PCMAX], rKept[PCMAX], rDst[PCMAX];
     double pcV[PCMAX];
     // pivot row, pivot column at slot 0 (kind 1), with the (begin,len,cap) of each column
     int tJ[PRMAX], tB[PRMAX], tL[PRMAX], tC[PRMAX], tNew[PRMAX];
-    double tX[PRMAX], tMx[PRMAX]; // pivot-row value of the column; its new maximum
+    double tX[PRMAX]; // pivot-row value of the column
     unsigned long long tM[PRMAX];
     // staged candidate entries
     int sI[STGMAX], sB[STGMAX], sL[STGMAX], sC[STGMAX];
     double sV[STGMAX];
     unsigned long long hRow[HROW]; // (row index << 32) | position, ~0 = empty: one LDS read per probe
     unsigned long long hCol[HCOL]; // (column index << 32) | slot in tJ, ~0 = empty
-    int ls[2][320]; // scratch of the batched list moves (0: column lists, 1: row lists)
     unsigned long long kg[2][KGMAX]; // key -> lanes with that key, all zero between list moves
 };
 
