@@ -91,7 +91,7 @@ def batched_throughput(args, c, dev, local_rank, world):
         h.close()
     return {"bases_in_flight_per_gpu": B, "workgroup_threads": args.batch_block, "nnz_per_s": world * nnz / el,
             "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
-            "roofline": {"bound": "hbm", "kernel": "k_pivot_loop (grid = %d workgroups)" % B, "achieved": gbs,
+            "roofline": {"bound": "hbm", "kernel": "k_pivot_loop_batch (grid = %d workgroups)" % B, "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
             "note": "throughput mode, reported beside the headline; `value` above is ONE basis per GPU"}
 
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1024, help="bases in flight for the secondary throughput measurement (0 = skip)")
+    ap.add_argument("--batch", type=int, default=1280, help="bases in flight for the secondary throughput measurement (0 = skip)")
     ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the pivot kernel in batch mode")
     args = ap.parse_args()
 

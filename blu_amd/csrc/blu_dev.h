@@ -55,7 +55,7 @@ struct Scalars {
     long long nexpand;
     long long ngarbage;
     long long d3_hits;    // cancellations at pivot-column position >= 32 (reference defect D3 would diverge)
-    long long npivot_kind[12]; // counters: 0 singleton row, 1 singleton col, 2 doubleton, 3 small, 4 any, 5 empty col
+    long long npivot_kind[6];  // counters: 0 singleton row, 1 singleton col, 2 doubleton, 3 small, 4 any, 5 empty col
                               // (6..11 spare)
     double min_pivot, max_pivot;
     double onenorm, infnorm;
@@ -165,7 +165,8 @@ struct DevG {
 // The COLD arrays -- touched only by the general pivot paths, or not at all in this kernel -- are
 // therefore not held: a ColdArr fetches its pointer from the descriptor (one scalar load) where it is used.
 template <class T> struct ColdArr {
-    GPTR(T *const) slot; // where the pointer sits inside the descriptor (global memory)
+    typedef T *ptr_t;
+    const __attribute__((address_space(1))) ptr_t *slot; // where the pointer sits inside the descriptor (global memory)
     __device__ __forceinline__ GPTR(T) get() const { return (GPTR(T))(*slot); }
     __device__ __forceinline__ operator GPTR(T)() const { return get(); }
     __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](int i) const { return get()[i]; }
@@ -191,7 +192,7 @@ struct DevGP {
 #define X(T, n) n((GPTR(T))d->n),
               DEVLU_ARRAYS_HOT(X)
 #undef X
-#define X(T, n) n{(GPTR(T *const)) & d->n},
+#define X(T, n) n{(const __attribute__((address_space(1))) ColdArr<T>::ptr_t *)&d->n},
                   DEVLU_ARRAYS_COLD(X)
 #undef X
                       s(d->s)

@@ -83,10 +83,10 @@ struct alignas(16) Sm {
     int stop_at, need_search;
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
-    long long kinds[12];
+    long long kinds[6];
     int sh[40];
     long long shl[20];
-    double swork[16 * 64];
+    double swork[16 * 64]; // one dense work column per wave; LAST member: the batch kernel allocates 4 of the 16
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1191,12 +1191,10 @@ __device__ COLD void setup_pivot_general(const DevGP &D, Sm *sm)
     }
 }
 
-__global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
+__device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
 {
     const DevGP D(&Ds[blockIdx.x]);
     Scalars *S = D.s;
-    __shared__ Sm smem;
-    Sm *sm = &smem;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const int m = D.m;
 
@@ -1222,12 +1220,12 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         sm->fa.kind = 0;
         sm->fa.ewFlag = 0;
         sm->fa.ewValid = 0;
-        for (int k = 0; k < 12; k++) sm->kinds[k] = 0;
+        for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
 #ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) sm->prof[k] = 0;
 #endif
     }
-    for (int k = tid; k < 16 * 64; k += blockDim.x) sm->swork[k] = 0.0;
+    for (int k = tid; k < (int)blockDim.x; k += blockDim.x) sm->swork[k] = 0.0; // num_waves() x 64
     for (int k = tid; k < 2 * KGMAX; k += blockDim.x) sm->fa.kg[0][k] = 0ull;
     if (tid == 0) g_pivot_err = 0;
     __syncthreads();
@@ -1400,10 +1398,29 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
         S->factor_flops += sm->flops;
         S->nexpand += sm->nexpand;
         S->d3_hits += sm->d3;
-        for (int k = 0; k < 12; k++) S->npivot_kind[k] += sm->kinds[k];
+        for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
 #ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) S->prof[k] += sm->prof[k];
 #endif
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }
+}
+
+// One matrix: all 16 waves of a CU, 128 VGPRs.
+__global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
+{
+    __shared__ Sm smem;
+    pivot_loop_body(Ds, stop_at, &smem);
+}
+// Many matrices (batch): workgroups of <= 256 threads = 4 waves, so only 4 of the 16 work columns at the
+// end of Sm are allocated, and a register budget for BLU_BATCH_WAVES waves per SIMD: that many
+// workgroups share a CU (LDS is handed out in 1280-byte granules: 160 KB / 6 -> 25 600 bytes each).
+#ifndef BLU_BATCH_WAVES
+#define BLU_BATCH_WAVES 6
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BLU_BATCH_WAVES, BLU_BATCH_WAVES)))
+k_pivot_loop_batch(DevLU *Ds, int stop_at)
+{
+    __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - 12 * 64 * sizeof(double)];
+    pivot_loop_body(Ds, stop_at, reinterpret_cast<Sm *>(raw));
 }

@@ -2,7 +2,7 @@
 #pragma once
 #define PCMAX 65    // cached pivot column entries (pivot_small: <= 64 off-diagonals)
 #define PRMAX 256   // cached pivot row entries
-#define STGMAX 192  // staged Markowitz candidate entries
+#define STGMAX 120  // staged Markowitz candidate entries
 #define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
 #define HROW 256    // hash slots, rows of the pivot column (<= 64 keys)
 #define HCOL 512    // hash slots, columns of the pivot row (<= 256 keys)
