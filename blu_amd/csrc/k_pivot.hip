@@ -1191,6 +1191,9 @@ __device__ COLD void setup_pivot_general(const DevGP &D, Sm *sm)
     }
 }
 
+// BATCH: the 4-wave workgroups of the batch kernel cannot spare a wave for the split list update and the
+// early search; leaving that code out also relieves its tighter register budget.
+template <bool BATCH>
 __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
 {
     const DevGP D(&Ds[blockIdx.x]);
@@ -1218,7 +1221,6 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
         sm->d3 = 0;
         sm->stop_at = stop_at;
         sm->fa.kind = 0;
-        sm->fa.ewFlag = 0;
         sm->fa.ewValid = 0;
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
 #ifdef BLU_PROFILE
@@ -1233,6 +1235,8 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
     // Three workgroup barriers per pivot: wave 0 alone runs [record previous pivot -> loop head -> search
     // + set-up] while the other waves wait at the barrier below; the pivot functions hold the other two
     // (after the line updates, after the finalize step).
+    long long ew_mcb = 0; // wave 0: per-lane result of the early search, kept for its next search
+    int ew_fb = 0;
     for (;;) {
         if (w == 0) {
             // ---- loop head: done / stop / error?
@@ -1251,7 +1255,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
             if (!sm->head_exit) {
                 bool handled = false;
                 if (sm->need_search) {
-                    if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast(D, sm);
+                    if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast<BATCH>(D, sm, ew_mcb, ew_fb);
                     if (!handled) {
                         if (D.search_rows == 0) markowitz_wave(D, sm);
                         else if (lane == 0) markowitz_serial(D, sm);
@@ -1293,8 +1297,8 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
         const int nz_col = dB.x, nz_row = dB.y;
         const int kind = dC.x;
         bool ok = true;
-        if (kind == 1) fast_small(D, sm, pr, pc, nz_col, nz_row);
-        else if (kind == 2) fast_scol(D, sm, pr, pc, nz_row, dC.y);
+        if (kind == 1) fast_small<BATCH>(D, sm, pr, pc, nz_col, nz_row, ew_mcb, ew_fb);
+        else if (kind == 2) fast_scol<BATCH>(D, sm, pr, pc, nz_row, dC.y, ew_mcb, ew_fb);
         else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
         else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
         else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
@@ -1410,7 +1414,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
     __shared__ Sm smem;
-    pivot_loop_body(Ds, stop_at, &smem);
+    pivot_loop_body<false>(Ds, stop_at, &smem);
 }
 // Many matrices (batch): workgroups of <= 256 threads = 4 waves, so only 4 of the 16 work columns at the
 // end of Sm are allocated, and a register budget for BLU_BATCH_WAVES waves per SIMD: that many
@@ -1422,5 +1426,5 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BLU_BA
 k_pivot_loop_batch(DevLU *Ds, int stop_at)
 {
     __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - 12 * 64 * sizeof(double)];
-    pivot_loop_body(Ds, stop_at, reinterpret_cast<Sm *>(raw));
+    pivot_loop_body<true>(Ds, stop_at, reinterpret_cast<Sm *>(raw));
 }

@@ -119,6 +119,96 @@ struct InHRow {
     }
 };
 
+// The batched list_move in two halves (n < 64 elements).  WHICH elements leave their lists is known as
+// soon as the pivot is chosen -- every column of the pivot row -- while their new lists (keys = new
+// counts) are known only after the line updates.  So the unlink half runs BESIDE the line updates, on a
+// wave of its own, and only the append half is left for the finalize step:
+//   wave_list_unlink_set  links of every element loaded together (one round trip); runs of moved
+//                         neighbours resolved by hash look-ups + pointer doubling over the lanes; the first
+//                         of each run links its unmoved predecessor to the run's unmoved successor;
+//                         `gone` (lane n) links to itself (list.rs:84-85)
+//   wave_list_append_set  (after a workgroup barrier: the unlink stores are complete) the tails in memory
+//                         ARE the real tails; lanes of equal key meet in the LDS key table; ordered
+//                         tail-append.  Returns the smallest key > 0.
+// skip = index in elems of an element that is not moved (the pivot column inside a singleton-column
+// pivot row, which is `gone`), or -1.
+template <class InSet>
+__device__ __forceinline__ void wave_list_unlink_set(gint_p flink, gint_p blink, const int *elems, int n, int skip, InSet inS, int gone)
+{
+    const int lane = lane_id();
+    const bool mov = lane < n && lane != skip;
+    const bool unl = mov || (lane == n && gone >= 0);
+    const int e = mov ? elems[lane] : (unl ? gone : 0);
+    int p = 0, nx = 0;
+    if (unl) {
+        p = blink[e];
+        nx = flink[e];
+    }
+    int sl, pl, dummy;
+    inS.lanes_of(nx, p, 0, unl, unl, false, n, sl, pl, dummy);
+    const bool first = unl && pl < 0; // first of a run of moved neighbours
+    int fs = nx;
+    for (int round = 0; round < 7; round++) {
+        if (!__ballot(sl >= 0)) break;
+        const int src = sl >= 0 ? sl : lane;
+        const int fs2 = __shfl(fs, src), sl2 = __shfl(sl, src);
+        if (sl >= 0) {
+            fs = fs2;
+            sl = sl2;
+        }
+    }
+    if (first) {
+        flink[p] = fs;
+        blink[fs] = p;
+    }
+    if (lane == n && gone >= 0) {
+        flink[gone] = gone;
+        blink[gone] = gone;
+    }
+}
+__device__ __forceinline__ int wave_list_append_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n, int big,
+                                                    unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
+{
+    const int lane = lane_id();
+    const int key = lane < n ? keys[lane] : -1;
+    const bool act = key >= 0;
+    const int e = act ? elems[lane] : 0;
+    int t = 0;
+    if (act) t = blink[nelem + key];
+    // while the load is in flight: neighbours inside the new list = nearest lanes below / above with the same key
+    unsigned long long mygrp = 0ull;
+    if (!__ballot(act && key >= KGMAX)) {
+        if (act) atomicOr(&kg[key], 1ull << lane);
+        wave_mem_sync();
+        if (act) {
+            mygrp = kg[key];
+            kg[key] = 0ull;
+        }
+    } else {
+        unsigned long long active = __ballot(act);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int k = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long grp = __ballot(act && key == k);
+            if (key == k) mygrp = grp;
+            active &= ~grp;
+        }
+    }
+    const unsigned long long below = mygrp & lanes_below(lane);
+    const unsigned long long above = lane < 63 ? mygrp & ~((2ull << lane) - 1ull) : 0ull;
+    const int prevl = below ? 63 - __clzll((long long)below) : -1;
+    const int nextl = above ? __ffsll((long long)above) - 1 : -1;
+    const int eprev = prevl >= 0 ? elems[prevl] : 0, enext = nextl >= 0 ? elems[nextl] : 0;
+    const int minall = wave_min_i(act && key > 0 ? key : big);
+    if (act) {
+        blink[e] = prevl >= 0 ? eprev : t;
+        flink[e] = nextl >= 0 ? enext : nelem + key;
+        if (prevl < 0) flink[t] = e;
+        if (nextl < 0) blink[nelem + key] = e;
+    }
+    return minall;
+}
+
 // Batched list_move (see wave_list_move_batch in k_pivot.hip) with the set of moved elements given
 // as a membership predicate instead of a mark array.  elems/keys may live in LDS.
 // `gone` (>= 0): one more element of the set that is only unlinked, not re-appended (the pivot
@@ -126,12 +216,10 @@ struct InHRow {
 template <class InSet>
 __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
                                         InSet inS, int big, int gone,
-                                        unsigned long long *kg /* KGMAX words of LDS, all zero between calls */,
-                                        Fast *pub /* or null: publish the unlinked runs for early_search */, int seq = 0)
+                                        unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
 {
     const int lane = lane_id();
     int minkey = big;
-    if (pub && n >= 64 && lane == 0) __hip_atomic_store(&pub->ewFlag, -seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (n < 64) {
         // Single pass, one memory round trip.  Lane n unlinks `gone`.
         // Single pass: the three loads per element (its two links and the tail of its new list) are
@@ -207,17 +295,6 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
                 fp = fp2;
                 pl = pl2;
             }
-        }
-        if (pub) { // the searching wave walks the lists while these stores are under way: tell it the new links
-            const unsigned long long fm = __ballot(first);
-            if (first) {
-                const int d = __popcll(fm & lanes_below(lane));
-                pub->ewP[d] = p;
-                pub->ewF[d] = fs;
-            }
-            if (lane == 0) pub->ewNP = __popcll(fm);
-            wave_mem_sync();
-            if (lane == 0) __hip_atomic_store(&pub->ewFlag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (first) { // link the run's unmoved predecessor to its unmoved successor
             flink[p] = fs;
@@ -598,16 +675,17 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
 
 // the complete search on the current list state.  Returns false if the shape is outside what this path
 // handles (nothing has been modified then; the caller runs the general search).
-__device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm)
+template <bool BATCH>
+__device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long ew_mcb, int ew_fb)
 {
     Fast *fa = &sm->fa;
     if (lane_id() == 0) fa->kind = 0;
     PROF_STAMP(8);
     int nsr = 0;
-    if (BLU_EARLY && fa->ewValid) { // found and staged while the previous pivot was being finished (early_search)
+    if (BLU_EARLY && !BATCH && fa->ewValid) { // found and staged while the previous pivot was being finished (early_search)
         const int lane = lane_id();
-        const long long mcb = fa->ewMcb[lane];
-        const int fb = fa->ewFb[lane];
+        const long long mcb = ew_mcb;
+        const int fb = ew_fb;
         nsr = fa->ewNsr;
         wave_mem_sync();
         if (lane == 0) fa->ewValid = 0;
@@ -787,7 +865,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *
         D.ccap[j] = newcap;
         D.colmax[j] = cmx;
         fa->tNew[q] = newlen;
-        if (BLU_EARLY) { // new begin and maximum: the early search of the next pivot reads them
+        if (BLU_EARLY && q < 64) { // new begin and maximum: the early search of the next pivot reads them
             fa->tB[q] = dst;
             fa->tMx[q] = cmx;
         }
@@ -948,25 +1026,21 @@ __device__ __forceinline__ void fast_write_l(const DevGP &D, Sm *sm)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Early search: the candidates of pivot k+1, found and staged by wave 0 WHILE the other waves finish
-// pivot k (U/L write-out, count-list update).  After the line updates of pivot k (barrier) everything
-// the next search reads is final -- column entries, line metadata -- except the count lists, which
-// the list wave is rewriting at that very moment.  The lists AFTER the update are nevertheless known:
-//   * an unmoved column keeps its place; its successor is the next unmoved one.  The list wave
-//     publishes, for every run of moved neighbours it unlinks, (unmoved predecessor or list head ->
-//     first unmoved successor); any other unmoved column's link in memory is not touched by the unlink
-//     stores;
-//   * the moved columns are re-appended behind ALL unmoved members of the list of their new count, in
-//     pivot-row order: their keys and order are in LDS (elems / keys).  A moved column met while
-//     following a link in memory is therefore an appended one: the unmoved part of that list has ended.
-// So the first maxsearch columns in search order are: for count c ascending, the unmoved members of list
-// c (links through memory, corrected by the published pairs), then the moved columns with new count c.
-// Not attempted (the ordinary search runs): a column became empty or numerically null, a cancellation
-// fix-up is pending, row search is on, the batch took the long path, fewer than 4 waves.
-// `make ewcheck` compares every early result with the ordinary search.
+// Early search: when the next pivot is a column singleton (half of all pivots of an LP basis), wave 0 finds
+// and stages it WHILE the other waves write out pivot k (U row, L column, tail-append of the moved
+// columns).  After the barrier that ends the line updates everything the next search reads is final --
+// column entries, line metadata, and the count lists with the columns of the pivot row already unlinked
+// (wave_list_unlink_set ran beside the line updates) -- except that those columns are being re-appended
+// at the tails of their new lists at this very moment.  The first column of list 1 AFTER the update is
+// nevertheless known: the head's link in memory if it leads to an unmoved column (an unmoved column
+// keeps its place; a moved one met there has just been appended: no unmoved member), else the first
+// column of the pivot row whose new count is 1 (new counts, begins and maxima are in LDS; moved columns
+// are appended in pivot-row order).  The result equals mk_express's; `make ewcheck` compares every early
+// result with the ordinary search.  Not attempted: a column became empty or numerically null, a
+// cancellation fix-up is pending, row search is on, the long form of the list update was taken.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *elems, const int *keys, const int *begs, const double *maxs,
-                                             int n)
+                                             int n, long long &ew_mcb, int &ew_fb)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -976,188 +1050,71 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *
     if (sm->flag_small || fa->anycancel) return;
     const int left = m - (sm->rank + 1) - sm->rankdef; // active columns at the next search
     if (left < 1) return;
-    // my moved column (lane q < n): new count, new begin, new maximum -- all in LDS since the line updates
+    // my moved column (lane q < n): its new count
     const int kq = lane < n ? keys[lane] : -1;
-    const int minnew = wave_min_i(kq >= 0 ? kq : m + 2);
-    if (minnew == 0) return; // an empty column: the ordinary search takes it (markowitz.rs:73-78)
-    int nz = sm->min_colnz < minnew ? sm->min_colnz : minnew;
-    if (nz < 1) nz = 1;
+    if (__ballot(kq == 0)) return; // an empty column: the ordinary search takes it (markowitz.rs:73-78)
+    int nsr = 0;
 
-    // ---- before the list wave has anything to say: the heads of 64 lists, which of these lists receive
-    // moved columns, and the metadata of the first column in line if that one is not moved (its place
-    // does not depend on the update)
-    const int k = nz + lane;
-    int h = k <= m ? D.cflink[m + k] : m + k;
-    if (lane == 0) fa->ewMask = 0ull;
-    wave_mem_sync();
-    if (kq >= nz && kq < nz + 64) atomicOr(&fa->ewMask, 1ull << (kq - nz));
-    wave_mem_sync();
-    const unsigned long long mv = fa->ewMask;
-    const bool hm = k <= m && h < m && hcol_has(fa, h); // first member moved: the list wave knows the new first one
-    const unsigned long long amb = __ballot(hm);
-    const unsigned long long um0 = __ballot(k <= m && h < m && !hm);
-    int j0 = -1, fl0 = 0, cb0 = 0, cl0 = 0;
-    double cmx0 = 0.0;
+    // ---- column singletons first (mk_express's case, half of all pivots): the head of list 1 if it is an
+    // unmoved column, else the first moved column whose new count is 1
     {
-        const unsigned long long any = um0 | amb | mv;
-        if (any) {
-            const int b0 = __ffsll((long long)any) - 1;
-            if ((um0 >> b0) & 1ull) {
-                j0 = __shfl(h, b0);
-                fl0 = D.cflink[j0];
-                cb0 = D.cbeg[j0];
-                cl0 = D.clen[j0];
-                cmx0 = D.colmax[j0];
+        const int h1 = D.cflink[m + 1];
+        const unsigned long long one = __ballot(kq == 1);
+        int j = -1, cb = 0;
+        double cmx = 0.0;
+        if (h1 < m && !hcol_has(fa, h1)) {
+            j = h1;
+            cb = D.cbeg[j];
+            cmx = D.colmax[j];
+            if (D.clen[j] != 1) return;
+        } else if (one) {
+            const int l = __ffsll((long long)one) - 1;
+            j = elems[l];
+            cb = begs[l];
+            cmx = maxs[l];
+        }
+        if (j >= 0) {
+            if (cmx == 0.0 || !(cmx >= D.abstol)) return;
+            const int idx = D.cidx[cb];
+            const double val = D.cval[cb];
+            const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+            const double tol = fmax(D.abstol, D.reltol * cmx);
+            const double x = fabs(val);
+            if (x == 0.0 || x < tol) return;
+            nsr = left < K ? left : K;
+            if (lane == 0) {
+                fa->ncand = 1;
+                fa->cJ[0] = j;
+                fa->cNz[0] = 1;
+                fa->cB[0] = cb;
+                fa->cL[0] = 1;
+                fa->cMx[0] = cmx;
+                fa->cOff[0] = 0;
+                fa->cOff[1] = 1;
+                fa->sI[0] = idx;
+                fa->sV[0] = val;
+                fa->sB[0] = rb;
+                fa->sL[0] = rl;
+                fa->sC[0] = rc;
+                fa->ewNsr = nsr;
+                fa->ewValid = 1;
             }
+            ew_mcb = 0;
+            ew_fb = 0;
+            wave_mem_sync();
+            return;
         }
     }
-    PROF_STAMP(41);
-    // ---- the list wave's pairs (unmoved predecessor or head -> first unmoved successor)
-    // (the flag carries the number of the pivot it belongs to: no reset, no stale value)
-    const int seq = sm->rank + 1;
-    int flag;
-    while ((flag = __hip_atomic_load(&fa->ewFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq && flag != -seq)
-        __builtin_amdgcn_s_sleep(1);
-    if (flag < 0) return;
-    PROF_STAMP(42);
-    const int np = fa->ewNP;
-    const int myP = lane < np ? fa->ewP[lane] : -1, myF = lane < np ? fa->ewF[lane] : 0;
-    if (amb) { // heads whose first member was moved
-        int *win = fa->ewWin;
-        win[lane] = -2;
-        wave_mem_sync();
-        if (myP >= m + nz && myP < m + nz + 64) win[myP - m - nz] = myF;
-        wave_mem_sync();
-        if (hm) h = win[lane] != -2 ? win[lane] : m + k; // (a head with a moved first member is always a predecessor)
-    }
-    const unsigned long long um = __ballot(k <= m && h < m);
-    unsigned long long ne = um | mv;
-    int ncand = 0, total = 0;
-    bool bad = false, express = false;
-    while (ne && ncand < K && !bad && !express) {
-        const int b = __ffsll((long long)ne) - 1;
-        ne &= ne - 1;
-        const int c = nz + b;
-        if ((um >> b) & 1ull) { // unmoved members of list c
-            int j = __shfl(h, b);
-            int guard = 0;
-            while (j < m && ncand < K) {
-                int fl, cb, cl;
-                double cmx;
-                if (j == j0) {
-                    fl = fl0;
-                    cb = cb0;
-                    cl = cl0;
-                    cmx = cmx0;
-                } else {
-                    fl = D.cflink[j];
-                    cb = D.cbeg[j];
-                    cl = D.clen[j];
-                    cmx = D.colmax[j];
-                }
-                if (cl != c || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > 8) {
-                    bad = true;
-                    break;
-                }
-                if (lane == 0) {
-                    fa->cJ[ncand] = j;
-                    fa->cNz[ncand] = c;
-                    fa->cB[ncand] = cb;
-                    fa->cL[ncand] = cl;
-                    fa->cMx[ncand] = cmx;
-                    fa->cOff[ncand] = total;
-                }
-                total += cl;
-                ncand++;
-                if (ncand == 1 && c == 1) {
-                    express = true;
-                    break;
-                }
-                const unsigned long long hit = __ballot(myP == j);
-                int nx = hit ? __builtin_amdgcn_readlane(myF, __ffsll((long long)hit) - 1) : fl;
-                if (nx < m && hcol_has(fa, nx)) nx = m + c; // an appended column: the unmoved part ends here
-                j = nx;
-            }
-        }
-        if (((mv >> b) & 1ull) && !bad && !express) { // then the moved columns whose new count is c, in pivot-row order
-            unsigned long long qb = __ballot(kq == c);
-            while (qb && ncand < K) {
-                const int l = __ffsll((long long)qb) - 1;
-                qb &= qb - 1;
-                const int j = elems[l], cb = begs[l];
-                const double cmx = maxs[l];
-                if (cmx == 0.0 || !(cmx >= D.abstol)) {
-                    bad = true;
-                    break;
-                }
-                if (lane == 0) {
-                    fa->cJ[ncand] = j;
-                    fa->cNz[ncand] = c;
-                    fa->cB[ncand] = cb;
-                    fa->cL[ncand] = c;
-                    fa->cMx[ncand] = cmx;
-                    fa->cOff[ncand] = total;
-                }
-                total += c;
-                ncand++;
-                if (ncand == 1 && c == 1) {
-                    express = true;
-                    break;
-                }
-            }
-        }
-    }
-    PROF_WAIT();
-    PROF_STAMP(43);
-    // fewer than maxsearch columns in this window of 64 counts: leave it to the ordinary search, unless
-    // these are all the columns there are
-    if (bad || ncand == 0 || (!express && ncand < K && ncand < left)) return;
-    int nsr;
-    long long mcb = 0;
-    int fb = 0;
-    if (express) { // column singleton first in line: mk_express's answer
-        const int cb = fa->cB[0];
-        const double cmx = fa->cMx[0];
-        const int idx = D.cidx[cb];
-        const double val = D.cval[cb];
-        const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
-        const double tol = fmax(D.abstol, D.reltol * cmx);
-        const double x = fabs(val);
-        if (x == 0.0 || x < tol) return;
-        nsr = left < K ? left : K;
-        if (lane == 0) {
-            fa->ncand = 1;
-            fa->cOff[1] = 1;
-            fa->sI[0] = idx;
-            fa->sV[0] = val;
-            fa->sB[0] = rb;
-            fa->sL[0] = rl;
-            fa->sC[0] = rc;
-        }
-    } else {
-        if (total > STGMAX) return;
-        if (lane == 0) {
-            fa->cOff[ncand] = total;
-            fa->ncand = ncand;
-        }
-        wave_mem_sync();
-        mk_stage(D, sm, mcb, fb);
-        nsr = ncand;
-    }
-    PROF_STAMP(44);
-    fa->ewMcb[lane] = mcb;
-    fa->ewFb[lane] = fb;
-    if (lane == 0) {
-        fa->ewNsr = nsr;
-        fa->ewValid = 1;
-    }
-    wave_mem_sync();
+    // No singleton: the full walk (3 dependent candidate loads, then the staging) takes ~8 000 cycles here
+    // against ~5 500 in the ordinary search and the 2 000 of the finalize step it would hide behind:
+    // measured as a net loss, so that case is left to the ordinary search.
 }
 
 // ------------------------------------------------------------------------------------------------
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int pc, int nzc, int nzr)
+template <bool BATCH>
+__device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int pc, int nzc, int nzr, long long &ew_mcb, int &ew_fb)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1173,12 +1130,19 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     // round the waves in reverse: the waves that got the last columns get no second column.
     const int ntask = rnz1 + cnz1;
     PROF_STAMP(4);
-    for (int base = 0; base < ntask; base += 3 * nw) {
+    // With 8 or more waves (the single-matrix configuration; a 4-wave batch workgroup cannot spare one) the
+    // last wave does not take line updates: it unlinks the columns of the pivot row from their count lists
+    // meanwhile (their new lists are known only after the updates: the append
+    // half follows in the finalize step).
+    const bool split = !BATCH && nw >= 8 && rnz1 < 64;
+    const int nwt = split ? nw - 1 : nw;
+    if (split && w == nw - 1) wave_list_unlink_set(D.cflink, D.cblink, fa->tJ + 1, rnz1, -1, InHCol{fa, 1, 0}, pc);
+    for (int base = 0; base < ntask && w < nwt; base += 3 * nwt) {
         int li[3], tt[3];
         double lv[3];
         tt[0] = base + w;
-        tt[1] = base + 2 * nw - 1 - w;
-        tt[2] = base + 2 * nw + w;
+        tt[1] = base + 2 * nwt - 1 - w;
+        tt[2] = base + 2 * nwt + w;
         // (begin, len) of the three lines first, unconditionally (slot 0 stands in for "no task"): the LDS
         // reads are independent and return together
         int lb[3], ll[3];
@@ -1239,8 +1203,8 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     // finalize step, one job per wave: [0] the search of the NEXT pivot (early_search), [1] L column,
     // [2] count lists, [3] U row and the pivot's own bookkeeping; with fewer than 4 waves (or row search)
     // wave 0 writes the U row instead and the next search waits for the barrier
-    const bool early = BLU_EARLY && nw >= 4 && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1);
+    const bool early = BLU_EARLY && split && !D.search_rows;
+    if (w == 0 && early) early_search(D, sm, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
     if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
         if (lane == 0) {
@@ -1257,8 +1221,9 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     }
     if (w == 2 % nw) {
         PROF_STAMP_L0(25);
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->kg[0],
-                                                early ? fa : nullptr, sm->rank + 1);
+        const int mn = split ? wave_list_append_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, m + 2, fa->kg[0])
+                             : wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc,
+                                                        fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
         PROF_WAIT();
         PROF_STAMP_L0(29);
@@ -1266,8 +1231,7 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     if (D.search_rows && w == 3 % nw) {
         if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->kg[1],
-                                                (Fast *)nullptr);
+        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->kg[1]);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
     __syncthreads();
@@ -1276,7 +1240,8 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
 // ------------------------------------------------------------------------------------------------
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc, int rl, int wq)
+template <bool BATCH>
+__device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc, int rl, int wq, long long &ew_mcb, int &ew_fb)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1284,7 +1249,12 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
     Fast *fa = &sm->fa;
     DEV_CHECK(S, fa->pcV[0] != 0.0 && fa->pcI[0] == pr);
 
-    for (int q = w; q < rl; q += nw) {
+    // (as in fast_small: with 8 or more waves the last one unlinks the row's columns from their count lists
+    // while the others take the column updates)
+    const bool split = !BATCH && nw >= 8 && rl < 64;
+    const int nwt = split ? nw - 1 : nw;
+    if (split && w == nw - 1) wave_list_unlink_set(D.cflink, D.cblink, fa->tJ, rl, wq, InHCol{fa, 0, wq}, pc);
+    for (int q = w; q < rl && w < nwt; q += nwt) {
         if (q == wq) {
             if (lane == 0) fa->tNew[q] = -1;
             continue;
@@ -1316,15 +1286,15 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
             D.clen[j] = cl - 1;
             D.colmax[j] = cmx;
             fa->tNew[q] = cl - 1;
-            if (BLU_EARLY) fa->tMx[q] = cmx;
+            if (BLU_EARLY && q < 64) fa->tMx[q] = cmx;
             fa->tX[q] = xrj;
             if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
         }
     }
     __syncthreads();
     // finalize step: [0] the search of the next pivot, [1] count lists, [2] U row and bookkeeping
-    const bool early = BLU_EARLY && nw >= 4 && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl);
+    const bool early = BLU_EARLY && split && !D.search_rows;
+    if (w == 0 && early) early_search(D, sm, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl, ew_mcb, ew_fb);
     if (w == (early ? 2 : 0)) {
         fast_write_u(D, sm, 0, rl - 1, wq);
         if (lane == 0) {
@@ -1338,8 +1308,8 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
     if (w == 1 % nw) {
         if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
         // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
-        const int mn = wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->kg[0],
-                                                early ? fa : nullptr, sm->rank + 1);
+        const int mn = split ? wave_list_append_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, m + 2, fa->kg[0])
+                             : wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
     }
     __syncthreads();

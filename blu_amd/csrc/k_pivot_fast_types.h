@@ -2,21 +2,18 @@
 #pragma once
 #define PCMAX 65    // cached pivot column entries (pivot_small: <= 64 off-diagonals)
 #define PRMAX 256   // cached pivot row entries
-#define STGMAX 120  // staged Markowitz candidate entries
+#define STGMAX 104  // staged Markowitz candidate entries
 #define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
 #define HROW 256    // hash slots, rows of the pivot column (<= 64 keys)
 #define HCOL 512    // hash slots, columns of the pivot row (<= 256 keys)
 #define KGMAX 128    // batched list moves: keys (new counts) below this meet in an LDS table
 #define HROW_BITS 8
 #define HCOL_BITS 9
-// Early search (early_search in k_pivot_fast.hip): wave 0 finds and stages the candidates of pivot k+1
-// while the other waves finish pivot k.  Correct (`make ewcheck` verifies every early result against the
-// ordinary search) but compiled out by default: the list update must publish its unlinked runs before
-// the walk can follow a link, so the early search ends ~12 000 cycles after the barrier where the
-// finalize step alone takes ~5 000 and the ordinary walk + staging ~4 200: 900 -> 972 ms on the 100k
-// benchmark basis.  -DBLU_EARLY=1 enables it.
+// Early search (early_search in k_pivot_fast.hip): when the next pivot is a column singleton, wave 0 finds
+// and stages it while the other waves write out the current pivot.  -DBLU_EARLY=0 switches it off; `make
+// ewcheck` builds a library that verifies every early result against the ordinary search.
 #ifndef BLU_EARLY
-#define BLU_EARLY 0
+#define BLU_EARLY 1
 #endif
 
 struct Fast {
@@ -28,15 +25,10 @@ struct Fast {
     double cMx[KCMAX];
     // early search: hand-over from the list wave (unlinked runs: predecessor -> first unmoved successor)
     // and the result kept for the next search
-    int ewFlag, ewNP, ewValid, ewNsr;
-    unsigned long long ewMask;
+    int ewValid, ewNsr;
 #if BLU_EARLY
-    int ewP[64], ewF[64], ewFb[64], ewWin[64];
-    long long ewMcb[64];
-    double tMx[PRMAX]; // new maximum of every column of the pivot row
+    double tMx[64]; // new maximum of the first 64 columns of the pivot row (the early search takes rows < 64 only)
 #else
-    int ewP[1], ewF[1], ewFb[1], ewWin[1]; // (the early search is compiled out: no LDS for it)
-    long long ewMcb[1];
     double tMx[1];
 #endif
     // pivot column, pivot at slot 0 (kind 1), with the (begin,len,cap) of each row
