@@ -551,7 +551,8 @@ __device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, int &nsearche
     return true;
 }
 
-__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, int fb, int nsearched)
+// single: one candidate entry (a column singleton): nothing to reduce
+__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, int fb, int nsearched, bool single)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -562,7 +563,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
     const long long BIG = 0x7fffffffffffffffLL;
     if (lane == 0) fa->kind = 0;
     // key = cost * 256 + position (position < STGMAX <= 256, cost < 2^55); first-seen entry wins ties
-    const long long bestkey = wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
+    const long long bestkey = single ? 0LL : wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
     wave_mem_sync();
     if (bestkey == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
         DEV_CHECK(S, false);
@@ -622,10 +623,13 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
     int wpos = -1;
 #pragma unroll
     for (int c = 0; c < PRMAX / 64; c++) {
-        const int q = c * 64 + lane;
-        jq[c] = q < nzr ? D.ridx[prb + q] : -1;
-        const unsigned long long hb = __ballot(jq[c] == pc);
-        if (hb) wpos = c * 64 + __ffsll((long long)hb) - 1;
+        jq[c] = -1;
+        if (c * 64 < nzr) { // (rows are mostly shorter than 64: one chunk)
+            const int q = c * 64 + lane;
+            jq[c] = q < nzr ? D.ridx[prb + q] : -1;
+            const unsigned long long hb = __ballot(jq[c] == pc);
+            if (hb) wpos = c * 64 + __ffsll((long long)hb) - 1;
+        }
     }
     if (wpos < 0) {
         DEV_CHECK(S, false);
@@ -633,13 +637,15 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
         return;
     }
     PROF_STAMP(12); // pivot column copied, pivot row loaded
-    for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
+    if (kind == 1) {
+        for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
+    }
     for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
     long long gc = 0, gr = 0;
 #pragma unroll
     for (int c = 0; c < PRMAX / 64; c++) {
         const int q = c * 64 + lane;
-        if (q < nzr) {
+        if (c * 64 < nzr && q < nzr) {
             const int j = jq[c];
             const int slot = kind == 1 ? ((q == wpos) ? 0 : (q == 0 ? wpos : q)) : q;
             const int tb = D.cbeg[j], tl = D.clen[j], tc = D.ccap[j];
@@ -661,8 +667,10 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
             const int n = fa->prL[p] + nzr - 1;
             gr += n + stretch_of(D.stretch, n) + D.pad;
         }
-        gc = wave_sum_ll(gc);
-        gr = wave_sum_ll(gr);
+        // one reduction for both room estimates (each below 2^31: <= 256 lines of < 2^22 entries)
+        const long long both = wave_sum_ll((gc << 32) | (gr & 0xffffffffLL));
+        gc = both >> 32;
+        gr = both & 0xffffffffLL;
         if ((long long)sm->cused + gc > (long long)D.carena_cap || (long long)sm->rused + gr > (long long)D.rarena_cap)
             kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
     }
@@ -722,13 +730,13 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long
 #endif
         PROF_STAMP(9);
         PROF_STAMP(10);
-        mk_pick(D, sm, mcb, fb, nsr);
+        mk_pick(D, sm, mcb, fb, nsr, true);
         return true;
     }
     if (mk_express(D, sm, nsr)) {
         PROF_STAMP(9);
         PROF_STAMP(10);
-        mk_pick(D, sm, 0, 0, nsr);
+        mk_pick(D, sm, 0, 0, nsr, true);
         return true;
     }
     const int r = mk_walk(D, sm);
@@ -739,7 +747,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long
     int fb;
     mk_stage(D, sm, mcb, fb);
     PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
-    mk_pick(D, sm, mcb, fb, fa->ncand);
+    mk_pick(D, sm, mcb, fb, fa->ncand, false);
     return true;
 }
 
