@@ -42,6 +42,9 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
         // with fewer than 4 waves the chains run one after the other on wave 0
         const bool mine = nw >= 4 ? (w == cc) : (w == 0);
         if (!mine) continue;
+#ifdef BLU_PROFILE
+        const long long t_chain0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         if (cc == 0) {
             // ---- condest(L): L' x = b with b = +-1 chosen on the fly, k descending (condest.rs:101-116, upper = 0)
             // This chain works in ROW-INDEX coordinates on the stage-ordered L columns (wl[i], i = row of B).
@@ -126,6 +129,9 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
                 }
             });
         }
+#ifdef BLU_PROFILE
+        if (lane == 0) printf("k_stats chain %d: %.1f ms at 2.1 GHz\n", cc, ((long long)__builtin_amdgcn_s_memtime() - t_chain0) / 2.1e6);
+#endif
     }
     __syncthreads();
 
