@@ -134,37 +134,29 @@ __global__ void __launch_bounds__(1024) k_solve_dense(DevLU *Ds, FinishOut *Os, 
     __syncthreads();
     if (wave_id() != 0) return;
 
+    const auto at_aux = [](int, const ColPtr &P) { return P.aux; };
+    const auto at_aux2 = [](int, const ColPtr &P) { return P.aux2; };
+    const auto sub_dot = [](int, const ColPtr &P, double dot, double own, bool &store) {
+        store = P.e > P.b;
+        return store ? own - dot : own;
+    };
     if (!trans) {
         const LtRows CL{lt_ptr, lt_idx, lt_val, D.prow, m};
-        sweep(CL, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-            if (P.e > P.b) {
-                const double x = col_dot(CL, P, E, y);
-                const double v = y[P.aux] - x;
-                wave_mem_sync();
-                if (lane == 0) y[P.aux] = v;
-            }
-        });
+        sweep_dot(CL, 0, 1, m, y, at_aux, sub_dot);
         const UColsRow CU{(gcll_p)O.u_colptr, (gcll_p)O.u_rowidx, (gcdouble_p)O.u_value, D.prow, D.pcol, m};
-        sweep(CU, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-            const double x = y[P.aux] / P.diag;
-            col_scatter<true>(CU, P, E, y, x);
+        sweep_scatter<true>(CU, m - 1, -1, m, y, at_aux, [&](int, const ColPtr &P, double own) {
+            const double x = own / P.diag;
             if (lane == 0) x_out[P.aux2] = x;
+            return x;
         });
     } else {
         const WRows CW{D.ubeg, D.uidx, D.qinv, D.prow, D.pcol, D.uval, (gcll_p)O.u_colptr, (gcdouble_p)O.u_value, m, rank};
-        sweep(CW, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-            const double x = y[P.aux2] / P.diag;
-            col_scatter<true>(CW, P, E, y, x);
+        sweep_scatter<true>(CW, 0, 1, m, y, at_aux2, [&](int, const ColPtr &P, double own) {
+            const double x = own / P.diag;
             if (lane == 0) x_out[P.aux] = x;
+            return x;
         });
         const LStage CS{D.lbeg, D.lidx, D.prow, nullptr, D.lval, m};
-        sweep(CS, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-            if (P.e > P.b) {
-                const double x = col_dot(CS, P, E, x_out);
-                const double v = x_out[P.aux] - x;
-                wave_mem_sync();
-                if (lane == 0) x_out[P.aux] = v;
-            }
-        });
+        sweep_dot(CS, m - 1, -1, m, x_out, at_aux, sub_dot);
     }
 }

@@ -45,88 +45,79 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
 #ifdef BLU_PROFILE
         const long long t_chain0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
+        const auto at_aux = [](int, const ColPtr &P) { return P.aux; };
+        const auto at_k = [](int k, const ColPtr &) { return k; };
         if (cc == 0) {
             // ---- condest(L): L' x = b with b = +-1 chosen on the fly, k descending (condest.rs:101-116, upper = 0)
             // This chain works in ROW-INDEX coordinates on the stage-ordered L columns (wl[i], i = row of B).
             double x1 = 0.0, xinf = 0.0;
-            sweep(CS, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+            sweep_dot(CS, m - 1, -1, m, wl, at_aux, [&](int, const ColPtr &P, double dot, double, bool &) {
                 double temp = 0.0;
-                if (P.e > P.b) temp = -col_dot(CS, P, E, wl); // temp -= work[i]*x
+                if (P.e > P.b) temp = -dot; // temp -= work[i]*x
                 temp += temp >= 0.0 ? 1.0 : -1.0;
-                if (lane == 0) wl[P.aux] = temp;
                 x1 += fabs(temp);
                 xinf = fmax(xinf, fabs(temp));
+                return temp;
             });
             // L y = x, k ascending, scatter (condest.rs:135-154)
             double y1 = 0.0;
-            sweep(CS, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                const double temp = wl[P.aux];
-                col_scatter<true>(CS, P, E, wl, temp);
-                y1 += fabs(temp);
+            sweep_scatter<true>(CS, 0, 1, m, wl, at_aux, [&](int, const ColPtr &, double own) {
+                y1 += fabs(own);
+                return own;
             });
             if (lane == 0) chain_out[0] = fmax(y1 / x1, xinf); // normest_l_inv
         } else if (cc == 1) {
             // ---- condest(U): U' x = b, k ascending, then U y = x, k descending (upper = 1, pivots = diagonal)
             double x1 = 0.0, xinf = 0.0;
-            sweep(CU, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
+            sweep_dot(CU, 0, 1, m, wu, at_k, [&](int, const ColPtr &P, double dot, double, bool &) {
                 double temp = 0.0;
-                if (P.e > P.b) temp = -col_dot(CU, P, E, wu);
+                if (P.e > P.b) temp = -dot;
                 temp += temp >= 0.0 ? 1.0 : -1.0;
                 temp /= P.diag;
-                if (lane == 0) wu[k] = temp;
                 x1 += fabs(temp);
                 xinf = fmax(xinf, fabs(temp));
+                return temp;
             });
             double y1 = 0.0;
-            sweep(CU, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                const double temp = wu[k] / P.diag;
-                wave_mem_sync(); // every lane has read wu[k] before lane 0 rewrites it
+            sweep_scatter<true>(CU, m - 1, -1, m, wu, at_k, [&](int k, const ColPtr &P, double own) {
+                const double temp = own / P.diag;
                 if (lane == 0) wu[k] = temp;
-                col_scatter<true>(CU, P, E, wu, temp);
                 y1 += fabs(temp);
+                return temp;
             });
             if (lane == 0) chain_out[1] = fmax(y1 / x1, xinf); // normest_u_inv
         } else if (cc == 2) {
             // ---- residual test, forward system (residual_test.rs:43-66): lhs = L\rhs with rhs = +-1 on the fly.
             // The reference takes row dots of L; the column scatter below adds the same products to each
             // accumulator in the same (ascending stage) order.  lf[k] first accumulates d, then holds lhs.
-            sweep(CL, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                const double d = lf[k];
+            sweep_scatter<false>(CL, 0, 1, m, lf, at_k, [&](int k, const ColPtr &, double own) {
+                const double d = own;
                 const double r = d <= 0.0 ? 1.0 : -1.0;
                 const double x = r - d;
-                wave_mem_sync();
                 if (lane == 0) {
                     rf[k] = r;
                     lf[k] = x;
                 }
-                col_scatter<false>(CL, P, E, lf, x);
+                return x;
             });
             // overwrite lhs by U\lhs, k descending (residual_test.rs:57-66)
-            sweep(CU, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                const double d = lf[k] / P.diag;
-                wave_mem_sync();
+            sweep_scatter<true>(CU, m - 1, -1, m, lf, at_k, [&](int k, const ColPtr &P, double own) {
+                const double d = own / P.diag;
                 if (lane == 0) lf[k] = d;
-                col_scatter<true>(CU, P, E, lf, d);
+                return d;
             });
         } else {
             // ---- residual test, backward system (residual_test.rs:85-108): lhs = U'\rhs, then L'\lhs
-            sweep(CU, 0, 1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                double d = 0.0;
-                if (P.e > P.b) d = col_dot(CU, P, E, lb);
+            sweep_dot(CU, 0, 1, m, lb, at_k, [&](int k, const ColPtr &P, double dot, double, bool &) {
+                const double d = P.e > P.b ? dot : 0.0;
                 const double r = d <= 0.0 ? 1.0 : -1.0;
-                if (lane == 0) {
-                    rb[k] = r;
-                    lb[k] = (r - d) / P.diag;
-                }
+                if (lane == 0) rb[k] = r;
+                return (r - d) / P.diag;
             });
             // dots with the stage-ordered L columns (rows mapped to positions), k descending
-            sweep(CSmap, m - 1, -1, m, [&](int k, const ColPtr &P, const ColEnt &E) {
-                if (P.e > P.b) {
-                    const double d = col_dot(CSmap, P, E, lb);
-                    const double v = lb[k] - d;
-                    wave_mem_sync();
-                    if (lane == 0) lb[k] = v;
-                }
+            sweep_dot(CSmap, m - 1, -1, m, lb, at_k, [&](int, const ColPtr &P, double dot, double own, bool &store) {
+                store = P.e > P.b;
+                return store ? own - dot : own;
             });
         }
 #ifdef BLU_PROFILE

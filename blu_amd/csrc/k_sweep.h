@@ -185,3 +185,132 @@ __device__ __forceinline__ void sweep(const Cols &C, int k0, int dir, int n, Bod
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same sweeps with the memory round trip taken OFF the step-to-step dependency.
+//
+// sweep_dot: step k forms  s_k = ordered dot(column k, x),  v_k = f(k, P_k, s_k, own_k)  and stores
+// x[w_k] = v_k.  The gather x[idx] of step k+1 is issued BEFORE step k is worked (entries two steps
+// ahead, pointers three); everything it reads is final except possibly x[w_k], and that value is in a
+// register when step k ends: the lanes of step k+1 whose index is w_k take it from there.  So a step costs
+// sum + f, not sum + f + a memory round trip.  own_k = x[w_k] before the sweep touches it (the sweeps
+// that subtract the dot from their own entry), fetched ahead likewise.
+// f: double f(int k, const ColPtr &P, double dot, double own, bool &store)
+// widx: int widx(int k, const ColPtr &P)   index of x the step writes (and the index space of the entries)
+// ------------------------------------------------------------------------------------------------
+template <class Cols, class WIdx, class F>
+__device__ __forceinline__ void sweep_dot(const Cols &C, int k0, int dir, int n, gdouble_p x, WIdx widx, F f)
+{
+    if (n <= 0) return;
+    const int lane = lane_id();
+    ColPtr Pa = C.ptr(k0);
+    C.diag(Pa);
+    ColEnt Ea = C.ent(Pa, 0);
+    ColPtr Pb = C.ptr(k0 + dir);
+    C.diag(Pb);
+    ColEnt Eb = C.ent(Pb, 0);
+    ColPtr Pc = C.ptr(k0 + 2 * dir);
+    double Ga = (lane < Pa.e - Pa.b) ? x[Ea.idx] : 0.0;
+    double owna = x[widx(k0, Pa)];
+    for (int s = 0, k = k0; s < n; s++, k += dir) {
+        // ahead: gather and own value of step k+1, entries of k+2, pointers of k+3
+        const int kb = k + dir;
+        const bool has_b = s + 1 < n;
+        const int wb = widx(kb, Pb);
+        double Gb = (has_b && lane < Pb.e - Pb.b) ? x[Eb.idx] : 0.0;
+        const double ownb = has_b ? x[wb] : 0.0;
+        C.diag(Pc);
+        const ColEnt Ec = C.ent(Pc, 0);
+        const ColPtr Pd = C.ptr(k + 3 * dir);
+        // step k
+        const long long len = Pa.e - Pa.b;
+        double dot = 0.0;
+        if (len > 0) {
+            const int n0 = len < 64 ? (int)len : 64;
+            dot = wave_ordered_sum(lane < n0 ? __dmul_rn(Ga, Ea.val) : 0.0, n0, 0.0);
+            for (long long off = 64; off < len; off += 64) { // long column: the rest straight from memory
+                const ColEnt E2 = C.ent(Pa, off);
+                const int n2 = (len - off) < 64 ? (int)(len - off) : 64;
+                dot = wave_ordered_sum(lane < n2 ? __dmul_rn(x[E2.idx], E2.val) : 0.0, n2, dot);
+            }
+        }
+        bool store = true;
+        const double v = f(k, Pa, dot, owna, store);
+        const int wa = widx(k, Pa);
+        if (store && lane == 0) x[wa] = v;
+        if (store && Eb.idx == wa) Gb = v; // the one value the early gather could not have seen
+        wave_mem_sync();
+        Pa = Pb;
+        Ea = Eb;
+        Ga = Gb;
+        owna = ownb;
+        Pb = Pc;
+        Eb = Ec;
+        Pc = Pd;
+    }
+}
+
+// sweep_scatter: step k takes  t_k = f(k, P_k, own_k)  (own_k = x[w_k] as the earlier steps left it) and
+// scatters  x[idx] -/+= t_k * val  over column k.  own_{k+1} is fetched before step k's scatter is issued
+// (it then reflects steps < k: a wave's memory operations are performed in order) and the one term step k
+// may add to it -- the lane of column k whose index is w_{k+1} -- is applied from registers with the same
+// two roundings.  The scatter itself stays a read-modify-write through memory, off the dependency chain.
+// f: double f(int k, const ColPtr &P, double own)   (may store the step's own results, e.g. x[w_k])
+// ------------------------------------------------------------------------------------------------
+template <bool SUB, class Cols, class WIdx, class F>
+__device__ __forceinline__ void sweep_scatter(const Cols &C, int k0, int dir, int n, gdouble_p x, WIdx widx, F f)
+{
+    if (n <= 0) return;
+    const int lane = lane_id();
+    ColPtr Pa = C.ptr(k0);
+    C.diag(Pa);
+    ColEnt Ea = C.ent(Pa, 0);
+    ColPtr Pb = C.ptr(k0 + dir);
+    C.diag(Pb);
+    ColEnt Eb = C.ent(Pb, 0);
+    ColPtr Pc = C.ptr(k0 + 2 * dir);
+    double owna = x[widx(k0, Pa)];
+    for (int s = 0, k = k0; s < n; s++, k += dir) {
+        const int kb = k + dir;
+        const bool has_b = s + 1 < n;
+        const int wb = widx(kb, Pb);
+        double ownb = has_b ? x[wb] : 0.0; // before this step's scatter is issued
+        C.diag(Pc);
+        const ColEnt Ec = C.ent(Pc, 0);
+        const ColPtr Pd = C.ptr(k + 3 * dir);
+        // step k
+        const double t = f(k, Pa, owna);
+        const long long len = Pa.e - Pa.b;
+        const bool mine = lane < len && Ea.idx >= 0; // (idx < 0: an entry the column set filters out)
+        if (mine) {
+            const double pr = __dmul_rn(t, Ea.val);
+            x[Ea.idx] = SUB ? __dsub_rn(x[Ea.idx], pr) : __dadd_rn(x[Ea.idx], pr);
+        }
+        const unsigned long long hit = __ballot(mine && Ea.idx == wb);
+        if (hit) { // step k changes the next step's own entry: the same update, from registers
+            const int l = __ffsll((long long)hit) - 1;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double_as_longlong(Ea.val), l);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(__double_as_longlong(Ea.val) >> 32), l);
+            const double pr = __dmul_rn(t, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)));
+            ownb = SUB ? __dsub_rn(ownb, pr) : __dadd_rn(ownb, pr);
+        }
+        if (len > 64) { // long column: the rest through memory, and the next own entry afterwards
+            for (long long off = 64; off < len; off += 64) {
+                const ColEnt E2 = C.ent(Pa, off);
+                if (off + lane < len && E2.idx >= 0) {
+                    const double pr = __dmul_rn(t, E2.val);
+                    x[E2.idx] = SUB ? __dsub_rn(x[E2.idx], pr) : __dadd_rn(x[E2.idx], pr);
+                }
+            }
+            wave_mem_sync();
+            if (has_b) ownb = x[wb];
+        }
+        wave_mem_sync();
+        Pa = Pb;
+        Ea = Eb;
+        owna = ownb;
+        Pb = Pc;
+        Eb = Ec;
+        Pc = Pd;
+    }
+}
