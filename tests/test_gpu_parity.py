@@ -455,3 +455,4 @@ def test_solve_dense_identical_to_oracle(blu, oracle, spec):
         for trans in "NT":
             b = rng.standard_normal(m)
             assert np.array_equal(g.solve_dense(b, trans), o.solve_dense(b, trans)), (singular, trans)
+
