@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- factorize throughput of the MI355X hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config C3|C2|C4]
 
-A "step" is one factorize (singletons -> setup_bump -> pivot loop -> build/read-out on the device) of
-one synthetic LP basis per GPU, with B already resident in HBM when the clock starts.  The workload
-is BASELINE.json configs[2] (C3: 100k x 100k, 10 nnz/col).  With N GPUs every rank factorizes its own
-basis (seed = 1 + rank): independent matrices, no data-path collective; RCCL is used
-only for the barriers around the timed region and the max-over-ranks of the elapsed time.
+A "step" is one factorize (singletons -> setup_bump -> pivot loop -> build/read-out -> statistics tail, all on
+the device) of one synthetic LP basis per GPU, with B already resident in HBM when the clock starts.  The
+default workload is BASELINE.json configs[2] (C3: 100k x 100k, 10 nnz/col); C4 is the 8 x 50k batch config
+(basis b -> rank b mod N).  With N GPUs every rank factorizes its own basis (seed = 1 + rank): independent
+matrices, no data-path collective; RCCL is used only for the barriers around the timed region
+and the max-over-ranks of the elapsed time.
+
+N > 1: when started WITHOUT a launcher (RANK unset) this script starts `python -m torch.distributed.run
+--nproc-per-node N ... bench.py ...` as a CHILD process -- before anything of torch.cuda / the HIP library is
+touched -- and exits with its return code.  Under a launcher WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,17 +28,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import blu_amd  # noqa: E402
-from blu_amd import keys as K, shard  # noqa: E402
-from blu_amd.matrices import CONFIGS  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pivot_loop_traffic.json")
 
 
-def cpu_baseline(cp, ri, v, budget_s=12.0, max_reps=12):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1280, help="bases in flight for the secondary throughput measurement (0 = skip)")
+    ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the pivot kernel in batch mode")
+    return ap.parse_args(argv)
+
+
+def kernel_source_sha16():
+    """Hash of the kernel sources the library is built from: the PMC traffic figure under profiles/ is only
+    quoted while it was measured on exactly these sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "blu_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cp, ri, v, label, budget_s=12.0, max_reps=12):
     """The CPU oracle (C restatement of the reference; the Rust crate cannot be built here) timed on ONE
     host core on the same matrix.  Bounded sample."""
     from oracle import orc  # baseline leg only
@@ -50,24 +74,27 @@ def cpu_baseline(cp, ri, v, budget_s=12.0, max_reps=12):
     times = sorted(times[1:] if len(times) > 1 else times)  # drop the warm-up run
     med = times[len(times) // 2]
     return {"value": len(ri) / med, "unit": "nnz/s", "cores": 1, "kind": "port",
-            "sample": "C3 basis, %d factorizations after 1 warm-up, median %.3f s each (single-threaded C restatement "
-                      "of blu 0.2.1 incl. its always-on consistency passes; reference crate not executable here)" % (len(times), med),
+            "sample": "%s basis, %d factorizations after 1 warm-up, median %.3f s each (single-threaded C restatement "
+                      "of blu 0.2.1 incl. its always-on consistency passes; reference crate not executable here)" % (label, len(times), med),
             "seconds_per_factorize": med}
 
 
-def batched_throughput(args, c, dev, local_rank, world):
+def batched_throughput(args, c, dev, local_rank, world, be):
     """SECONDARY measurement (never `value`): B independent bases of the same configuration in flight
     on this GPU, one workgroup per basis (blu_hip_factorize_batch).  A single factorize is a chain of
     dependent pivots and can not use more than one CU; this is the mode in which the chip fills up.
     8 distinct matrices (seeds) are cycled over the B handles; inputs resident in HBM."""
+    import numpy as np
+    import torch
+    from blu_amd import keys as K, shard
     B = args.batch
     nd = min(B, 8)
     mats = []
     for s in range(nd):
-        cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], 1000 + s, c["offscale"])
+        cp, ri, v = be.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], 1000 + s, c["offscale"])
         mats.append((torch.from_numpy(cp.view(np.int64)).to(dev), torch.from_numpy(ri.view(np.int64)).to(dev),
                      torch.from_numpy(v).to(dev), len(ri)))
-    hs = [blu_amd.BLU(c["m"], mats[k % nd][3] // 2, device=local_rank) for k in range(B)]
+    hs = [be.BLU(c["m"], mats[k % nd][3] // 2, device=local_rank) for k in range(B)]
     ptrs = [(mats[k % nd][0].data_ptr(), mats[k % nd][0].data_ptr() + 8, mats[k % nd][1].data_ptr(),
              mats[k % nd][2].data_ptr(), mats[k % nd][3]) for k in range(B)]
     nnz = sum(p[4] for p in ptrs)
@@ -75,7 +102,7 @@ def batched_throughput(args, c, dev, local_rank, world):
     for rep in range(3):  # rep 0 warms up (storage growth), best of the other two
         shard.fence(dev)
         t0 = time.perf_counter()
-        st = blu_amd.factorize_batch(hs, device_ptrs=ptrs, block=args.batch_block)
+        st = be.factorize_batch(hs, device_ptrs=ptrs, block=args.batch_block)
         shard.fence(dev)
         el = time.perf_counter() - t0
         if any(s != K.OK for s in st):
@@ -89,41 +116,65 @@ def batched_throughput(args, c, dev, local_rank, world):
     gbs = (32.0 * F + 32.0 * lu) / t_piv / 1e9
     for h in hs:
         h.close()
+    traffic = None
+    tinfo = _traffic_record("k_pivot_loop_batch")
+    if tinfo and tinfo.get("bases") == B and tinfo.get("config") == args.config:
+        traffic = tinfo["hbm_bytes_per_launch"] / max(t_piv / max(nl, 1), 1e-12) / 1e9
     return {"bases_in_flight_per_gpu": B, "workgroup_threads": args.batch_block, "nnz_per_s": world * nnz / el,
             "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
             "roofline": {"bound": "hbm", "kernel": "k_pivot_loop_batch (grid = %d workgroups)" % B, "achieved": gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic},
             "note": "throughput mode, reported beside the headline; `value` above is ONE basis per GPU"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3")
-    ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1280, help="bases in flight for the secondary throughput measurement (0 = skip)")
-    ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the pivot kernel in batch mode")
-    args = ap.parse_args()
+def _traffic_record(kernel):
+    """PMC traffic of `kernel` from profiles/pivot_loop_traffic.json -- only if it was measured on the kernel
+    sources this library is built from (PMC can not be collected from inside this script)."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernel_source_sha16") != kernel_source_sha16():
+        return None  # stale: the kernels changed since the counters were collected
+    return rec.get("kernels", {}).get(kernel)
+
+
+def rank_main(args, backend=None, device=None):
+    """What one rank does.  backend: the module that provides BLU / gen_lp_basis / factorize_batch (blu_amd on
+    the GPU; tests/test_shard_gloo.py passes a CPU stand-in to execute the N > 1 code path -- seeds, barriers,
+    MAX over ranks, the JSON line -- under gloo)."""
+    import numpy as np
+    import torch
+    from blu_amd import keys as K, shard
+    from blu_amd.matrices import CONFIGS
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start one process per GPU, or run without a launcher)" % (args.gpus, world))
+    stub = backend is not None
+    if not stub:
+        import blu_amd as backend
     dist = world > 1
-    if dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as td
-        torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import torch.distributed as td
+    if stub:
+        dev = device if device is not None else torch.device("cpu")
+        if dist and not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group("gloo")
     else:
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", local_rank)
+        if dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group("nccl", device_id=dev)
 
     c = dict(CONFIGS[args.config])
-    c["seed"] = shard.seed_of_basis(c, shard.bases_of_rank(world, rank, world)[0])  # independent bases, one per GPU
-    cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+    n_bases = 8 if args.config == "C4" else world
+    mine = shard.bases_of_rank(max(n_bases, world), rank, world)
+    c["seed"] = shard.seed_of_basis(c, mine[0])  # independent bases, one per GPU (C4 at N < 8: the first of this rank's share)
+    cp, ri, v = backend.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
     m, nnz = c["m"], len(ri)
 
     # inputs resident in HBM before the clock starts (uint64 bit patterns carried in int64 tensors)
@@ -131,7 +182,7 @@ def main():
     d_ri = torch.from_numpy(ri.view(np.int64)).to(dev)
     d_v = torch.from_numpy(v).to(dev)
     p_begin, p_end = d_cp.data_ptr(), d_cp.data_ptr() + 8
-    h = blu_amd.BLU(m, nnz, device=local_rank)
+    h = backend.BLU(m, nnz, device=local_rank)
     if args.block:
         h.dbg_set_block(args.block)
 
@@ -141,7 +192,7 @@ def main():
             raise RuntimeError("factorize status %d" % st)
 
     def fence():
-        shard.fence(dev)  # barrier (RCCL) + torch.cuda.synchronize()
+        shard.fence(dev)  # barrier (RCCL / gloo) + torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -157,6 +208,7 @@ def main():
         nlaunch += int(h.stat(K.STAT_DEV_RELAUNCHES))
     fence()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    total_nnz = shard.sum_over_ranks(nnz, dev)
 
     F = h.stat(K.STAT_FACTOR_FLOPS)
     l_nz, u_nz = h.stat(K.STAT_L_NZ), h.stat(K.STAT_U_NZ)
@@ -165,16 +217,19 @@ def main():
     bytes_elim = 32.0 * F + 32.0 * (l_nz + u_nz)
     bytes_all = 16.0 * (nnz + m) + bytes_elim
     t_kernel = t_pivot / max(1, nlaunch)  # average k_pivot_loop launch
-    # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this command,
-    # recorded under profiles/ (PMC can not be collected from inside this script)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pivot_loop_traffic.json")
-    if args.config == "C3" and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["hbm_bytes_per_launch"] / max(t_kernel, 1e-12) / 1e9
+    tinfo = _traffic_record("k_pivot_loop")
+    if tinfo and tinfo.get("config") == args.config:
+        traffic = tinfo["hbm_bytes_per_launch"] / max(t_kernel, 1e-12) / 1e9
     achieved = bytes_elim * args.steps / max(t_pivot, 1e-12) / 1e9
+    phases = {}
+    for name, key in (("k_prep", 44), ("k_setup", 45), ("k_finish", 46), ("k_stats", 47)):
+        val = h.stat(key)
+        if val == val and val > 0:
+            phases[name + "_ms"] = 1e3 * val
     out = {
-        "metric": "factorize nnz/s + achieved HBM GB/s, 100k x 100k 10-nnz/col basis",
-        "value": world * nnz * args.steps / elapsed,
+        "metric": "factorize nnz/s + achieved HBM GB/s, %dk x %dk %d-nnz/col basis" % (m // 1000, m // 1000, c["k"]),
+        "value": total_nnz * args.steps / elapsed,
         "unit": "nnz/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -185,29 +240,49 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: single %dx%d synthetic LP basis per GPU (lp_basis k=%d bw=%d tri_frac=%g offscale=%g seed=1+rank), "
-                               "nnz=%d, inputs resident in HBM" % (args.config, m, m, c["k"], c["bw"], c["tri_frac"], c["offscale"], nnz),
+        "config": {"workload": "%s: single %dx%d synthetic LP basis per GPU (lp_basis k=%d bw=%d tri_frac=%g offscale=%g seed=%d+basis), "
+                               "nnz=%d, inputs resident in HBM" % (args.config, m, m, c["k"], c["bw"], c["tri_frac"], c["offscale"],
+                                                                  CONFIGS[args.config]["seed"], nnz),
                    "m": m, "nnz": nnz, "l_nz": l_nz, "u_nz": u_nz, "factor_flops": F,
                    "rank": h.stat(K.STAT_RANK), "bump_size": h.stat(K.STAT_BUMP_SIZE),
                    "nsearch_pivot": h.stat(K.STAT_NSEARCH_PIVOT), "parallelism": "one basis per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "k_pivot_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pivot_loop_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch / avg launch time, GB/s)",
+                     "traffic_source": ("profiles/pivot_loop_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch / avg launch time, GB/s)"
+                                        if traffic is not None else "none valid for these kernel sources (profiles/pivot_loop_traffic.json is "
+                                        "keyed by the hash of blu_amd/csrc; re-collect with tools/pmc_traffic.sh)"),
                      "algorithmic_bytes_per_launch": bytes_elim * args.steps / max(1, nlaunch),
                      "avg_launch_ms": 1e3 * t_kernel, "launches_per_step": nlaunch / args.steps},
         "achieved_GBs_whole_factorize": bytes_all * args.steps / elapsed / 1e9,
         "device_ms_per_step": 1e3 * t_dev / args.steps,
+        "phases_last_step": phases,
     }
-    if args.batch > 0:
-        out["batched"] = batched_throughput(args, c, dev, local_rank, world)
+    if args.batch > 0 and not stub:
+        out["batched"] = batched_throughput(args, c, dev, local_rank, world, backend)
     if rank == 0 and not args.no_cpu_baseline:
-        cp0, ri0, v0 = (cp, ri, v) if not dist else blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], CONFIGS[args.config]["seed"], c["offscale"])
-        out["cpu_baseline"] = cpu_baseline(cp0, ri0, v0)
+        c0 = CONFIGS[args.config]
+        cp0, ri0, v0 = (cp, ri, v) if c["seed"] == c0["seed"] else backend.gen_lp_basis(c0["m"], c0["k"], c0["bw"], c0["tri_frac"], c0["seed"], c0["offscale"])
+        out["cpu_baseline"] = cpu_baseline(cp0, ri0, v0, args.config)
+        out["vs_cpu_baseline_per_gpu"] = (out["value"] / world) / out["cpu_baseline"]["value"]
     if dist:
         td.barrier()
-        td.destroy_process_group()
+        if not stub:
+            td.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return out if rank == 0 else None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # No launcher: start one as a child process, before this process has touched the GPU in any way
+        # (nothing of torch.cuda or libblu_hip has been imported or called so far), and hand its return code on.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank_main(args)
 
 
 if __name__ == "__main__":

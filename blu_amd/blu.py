@@ -134,9 +134,12 @@ def factorize_batch(handles, mats=None, device_ptrs=None, block=None):
             keep.append((cp, ri, v))
             pb[k], pe[k], pi[k], px[k], ln[k] = cp.ctypes.data, cp.ctypes.data + 8, ri.ctypes.data, v.ctypes.data, len(ri)
         on_dev = 0
-    st = (C.c_int * n)()
+    UNTOUCHED = -12345
+    st = (C.c_int * n)(*([UNTOUCHED] * n))
     rc = L.blu_hip_factorize_batch(hs, n, pb, pe, pi, px, ln, on_dev, st)
     out = [int(s) for s in st]
+    if rc < 0 and any(s == UNTOUCHED for s in out):  # refused before any handle was worked on
+        raise BluError(rc, handles[0].last_error())
     if rc in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY) and all(s >= 0 for s in out):
         raise BluError(rc, handles[0].last_error())
     for h, s in zip(handles, out):

@@ -72,6 +72,7 @@ struct Scalars {
     X(int, pad)                                                                                        \
     X(int, search_rows)                                                                                \
     X(int, no_fast)     /* debug: 1 = general pivot paths only (k_pivot_fast.hip off) */               \
+    X(int, skip_stats)  /* 1 = k_stats leaves this handle alone (blu_hip_set_skip_stats) */            \
     X(double, droptol)                                                                                 \
     X(double, abstol)                                                                                  \
     X(double, reltol)                                                                                  \

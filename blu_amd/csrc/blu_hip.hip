@@ -66,6 +66,7 @@ struct blu_hip {
     hipStream_t stream;
     hipEvent_t ev[4];
     double t_total, t_pivot;
+    double t_phase[4]; // k_prep, k_setup, k_finish, k_stats of the last factorize (seconds, HIP events)
     int relaunches;
     int block_threads; // workgroup size of the pivot kernel
     int no_fast;       // debug: disable the LDS fast paths
@@ -137,6 +138,7 @@ static bool upload_desc(blu_hip *h)
     D.pad = (int)h->pad;
     D.search_rows = (int)h->search_rows;
     D.no_fast = h->no_fast;
+    D.skip_stats = h->skip_stats;
     D.droptol = h->droptol;
     D.abstol = h->abstol;
     D.reltol = h->reltol;
@@ -347,6 +349,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_W_MEM: return (double)h->D.carena_cap + (double)h->D.rarena_cap;
     case BLU_STAT_L_FLOPS: return (double)h->sp_l_flops;
     case BLU_STAT_U_FLOPS: return (double)h->sp_u_flops;
+    case 44: case 45: case 46: case 47: return h->t_phase[key - 44]; // device seconds of k_prep / k_setup / k_finish / k_stats
     case 43: return (double)h->sp_branch; // branch of the last solve_sparse: 1 sparse, 2 sequential
     case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;
     case BLU_STAT_DEV_TIME_TOTAL: return h->t_total;

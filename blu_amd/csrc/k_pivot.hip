@@ -21,6 +21,7 @@
 // A failed check also raises this LDS flag, so the pivot loop can stop at the next pivot boundary
 // without polling the status word in HBM every iteration.
 __shared__ int g_pivot_err;
+__shared__ int g_pivot_err_line; // source line of a bounded loop that overran (k_pivot_fast.hip: probe_overrun)
 #undef DEV_CHECK
 #define DEV_CHECK(S, cond)                               \
     do {                                                 \
@@ -1229,7 +1230,10 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
     }
     for (int k = tid; k < (int)blockDim.x; k += blockDim.x) sm->swork[k] = 0.0; // num_waves() x 64
     for (int k = tid; k < 2 * KGMAX; k += blockDim.x) sm->fa.kg[0][k] = 0ull;
-    if (tid == 0) g_pivot_err = 0;
+    if (tid == 0) {
+        g_pivot_err = 0;
+        g_pivot_err_line = 0;
+    }
     __syncthreads();
 
     // Three workgroup barriers per pivot: wave 0 alone runs [record previous pivot -> loop head -> search
@@ -1406,6 +1410,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
 #ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) S->prof[k] += sm->prof[k];
 #endif
+        if (sm->exit_code == ST_ERROR && g_pivot_err_line) set_error(S, ST_ERROR, g_pivot_err_line);
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }
 }

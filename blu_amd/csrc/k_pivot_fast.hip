@@ -20,45 +20,60 @@
 // the general paths, which remain the fallback for all other shapes.
 
 __device__ __forceinline__ unsigned hslot(int k, int bits) { return ((unsigned)k * 2654435761u) >> (32 - bits); }
+// Every probe sequence is bounded by the table size: the tables are sized for at most half load (PCMAX - 1
+// keys in HROW slots, PRMAX keys in HCOL slots), so a sequence that visits every slot without finding the
+// key or an empty slot means a violated invariant.  That raises the pivot loop's error flag (the loop
+// leaves with ST_ERROR at the next pivot boundary) instead of spinning.
+__device__ __forceinline__ void probe_overrun(int line)
+{
+    g_pivot_err = 1;
+    g_pivot_err_line = line;
+}
 __device__ __forceinline__ void hrow_insert(Fast *f, int k, int v)
 {
-    unsigned s = hslot(k, 8);
+    unsigned s = hslot(k, HROW_BITS);
     const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)v;
-    for (;;) {
+    for (int n = 0; n < HROW; n++) {
         const unsigned long long old = atomicCAS(&f->hRow[s], ~0ull, want);
         if (old == ~0ull || (int)(old >> 32) == k) return;
         s = (s + 1) & (HROW - 1);
     }
+    probe_overrun(__LINE__);
 }
 __device__ __forceinline__ int hrow_lookup(const Fast *f, int k)
 {
-    unsigned s = hslot(k, 8);
-    for (;;) {
+    unsigned s = hslot(k, HROW_BITS);
+    for (int n = 0; n < HROW; n++) {
         const unsigned long long x = f->hRow[s];
         if ((int)(x >> 32) == k) return (int)(x & 0xffffffffull);
         if (x == ~0ull) return 0;
         s = (s + 1) & (HROW - 1);
     }
+    probe_overrun(__LINE__);
+    return 0;
 }
 __device__ __forceinline__ void hcol_insert(Fast *f, int k, int slot)
 {
     unsigned s = hslot(k, HCOL_BITS);
     const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)slot;
-    for (;;) {
+    for (int n = 0; n < HCOL; n++) {
         const unsigned long long old = atomicCAS(&f->hCol[s], ~0ull, want);
         if (old == ~0ull || (int)(old >> 32) == k) return;
         s = (s + 1) & (HCOL - 1);
     }
+    probe_overrun(__LINE__);
 }
 __device__ __forceinline__ bool hcol_has(const Fast *f, int k)
 {
     unsigned s = hslot(k, HCOL_BITS);
-    for (;;) {
+    for (int n = 0; n < HCOL; n++) {
         const unsigned long long x = f->hCol[s];
         if ((int)(x >> 32) == k) return true;
         if (x == ~0ull) return false;
         s = (s + 1) & (HCOL - 1);
     }
+    probe_overrun(__LINE__);
+    return false;
 }
 // Three look-ups at once in a table of (key << 32 | value) words: the probes of the three keys are
 // issued together, so the whole costs about one LDS round trip.  r = value, or -1 if the key is absent
@@ -71,7 +86,12 @@ __device__ __forceinline__ void hash_find3(const unsigned long long *H, int k1, 
     unsigned s1 = hslot(k1, BITS), s2 = hslot(k2, BITS), s3 = hslot(k3, BITS);
     r1 = r2 = r3 = -1;
     bool d1 = !w1, d2 = !w2, d3 = !w3;
+    int n = 0;
     while (!(d1 && d2 && d3)) {
+        if (++n > (1 << BITS)) {
+            probe_overrun(__LINE__);
+            break;
+        }
         const unsigned long long x1 = H[s1], x2 = H[s2], x3 = H[s3];
         if (!d1) {
             if ((int)(x1 >> 32) == k1) r1 = (int)(x1 & 0xffffffffull);

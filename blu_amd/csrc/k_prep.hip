@@ -72,10 +72,16 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             else if (e - b > 0x7fffffffull || e > (unsigned long long)D.b_i_len) bad = 1; // outside the caller's b_i/b_x
             else len = (int)(e - b);
         }
+        // the chunk total in 64 bits FIRST: up to 1024 lengths of up to 2^31-1 each (columns may overlap) can wrap
+        // a 32-bit scan, and a wrapped total would pass the range check below
+        const long long tot64 = block_sum_ll((long long)len, shl);
+        if ((long long)base + tot64 > 0x7fffffffLL) {
+            bad = 1;
+            break; // (uniform: every thread sees the same total)
+        }
         int tot;
         int ex = block_excl_scan_i(len, sh, &tot);
         if (j < m) D.bc_ptr[j] = base + ex;
-        if ((long long)base + tot > 0x7fffffffLL) bad = 1;
         base += tot;
     }
     bad = block_or_i(bad, sh);

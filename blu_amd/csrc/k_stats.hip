@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
     __shared__ double chain_out[16];
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), lane = lane_id(), nw = num_waves();
     const int m = D.m;
-    if (S->status != ST_DONE) return;
+    if (S->status != ST_DONE || D.skip_stats) return;
     const int rank = S->rank;
     // six m-vectors in the (all-zero) pivot_any work area; re-zeroed at the end
     gdouble_p wl = D.gwork, wu = D.gwork + (size_t)(m + 1), lf = D.gwork + 2 * (size_t)(m + 1),

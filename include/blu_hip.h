@@ -149,7 +149,11 @@ int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *irhs, const 
 /* Batch extension (no reference counterpart; the reference's only parallel
  * axis is independent BLU objects).  Factorizes n handles that
  * live on the same device concurrently, one workgroup per handle.  Matrix k is
- * given by the k-th pointers.  status[k] receives the per-handle status. */
+ * given by the k-th pointers.  status[k] receives the per-handle status (also when the call as a whole
+ * is refused: then every status[k] carries the refusal and no handle keeps usable factors).  The same
+ * handle may not appear twice and all handles must live on one device (BLU_ERROR_INVALID_ARGUMENT).
+ * Parameters and blu_hip_set_skip_stats are honoured per handle; the workgroup size of the batch
+ * (a debug knob) is taken from h[0]. */
 int blu_hip_factorize_batch(blu_hip **h, int n,
                             const uint64_t *const *b_begin, const uint64_t *const *b_end,
                             const uint64_t *const *b_i, const double *const *b_x,

@@ -49,7 +49,10 @@ enum {
     ORC_ERROR_SINGULAR_UPDATE = -6,
     /* not in the reference: returned by orc_factorize when the debug hook
      * stop_after_pivots fired (test infrastructure for step-wise comparison) */
-    ORC_STOPPED = 100
+    ORC_STOPPED = 100,
+    /* not in the reference: orc_blu_factorize met the endless Reallocate loop of defect D5 (W grown in the
+     * middle of the bump; the reference would grow W until the process dies) and gave up */
+    ORC_D5_TRAP = -98
 };
 
 /* Task (src/lu/def.rs:6-12) */
@@ -111,6 +114,8 @@ typedef struct orc_lu {
                          panics can still be compared with the HIP path */
     lu_int d3_hits;   /* cancellations recorded at pivot-column position >= 32:
                          0 means the faithful and the fixed runs are identical */
+    lu_int npivot_kind[6]; /* pivots taken per path: 0 singleton row, 1 singleton col, 2 doubleton col,
+                              3 small, 4 any, 5 empty column (factorize_bump.rs:24-33) */
     lu_int stop_after_pivots; /* <0: off; else factorize_bump returns
                                  ORC_STOPPED once rank+rankdef reaches it */
 } orc_lu;

@@ -15,6 +15,7 @@ _LIB = None
 OK, REALLOCATE, WARNING_SINGULAR_MATRIX = 0, 1, 2
 ERROR_INVALID_CALL, ERROR_ARGUMENT_MISSING, ERROR_INVALID_ARGUMENT = -2, -3, -4
 STOPPED = 100
+D5_TRAP = -98  # the reference's endless Reallocate loop (defect D5) was met: re-run with a larger initial capacity
 
 _i64p = C.POINTER(C.c_int64)
 _u64p = C.POINTER(C.c_uint64)
@@ -109,10 +110,25 @@ class OracleBLU:
         return bb, be, bi, bx
 
     def factorize(self, b_begin, b_end, b_i, b_x):
-        """BLU::factorize (blu.rs:95): realloc loop included."""
+        """BLU::factorize (blu.rs:95): realloc loop included.  Returns D5_TRAP where the reference would grow W
+        for ever (see oracle/orc_api.c); use factorize_roomy() to have the capacity raised until it does not."""
         self._keep = self._prep(b_begin, b_end, b_i, b_x)
         bb, be, bi, bx = self._keep
         return lib().orc_blu_factorize(self._h, _p(bb, _u64p), _p(be, _u64p), _p(bi, _u64p), _p(bx, _f64p))
+
+    @classmethod
+    def factorize_roomy(cls, m, cap, b_begin, b_end, b_i, b_x, setup=None, max_cap=1 << 28):
+        """A fresh OracleBLU(m, cap) factorized; on D5_TRAP the capacity is multiplied by 8 and the run repeated
+        (results do not depend on the storage layout).  setup(o) applies parameters / hooks.
+        Returns (oracle, status)."""
+        while True:
+            o = cls(m, cap)
+            if setup:
+                setup(o)
+            st = o.factorize(b_begin, b_end, b_i, b_x)
+            if st != D5_TRAP or cap >= max_cap:
+                return o, st
+            cap = min(max_cap, cap * 8)
 
     def factorize_raw(self, b_begin, b_end, b_i, b_x, c0ntinue=False):
         """factorize() (factorize.rs:34) without the realloc loop."""

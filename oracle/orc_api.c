@@ -170,9 +170,23 @@ int orc_blu_factorize(orc_blu *obj, const uint64_t *b_begin, const uint64_t *b_e
 {
     int c0ntinue = 0;
     int result;
+    lu_int stuck_rank = -1, stuck = 0;
     for (;;) {
         result = orc_factorize(&obj->lu, b_begin, b_end, b_i, b_x, c0ntinue);
         if (result == ORC_REALLOCATE) {
+            /* Test-harness guard, not in the reference.  D5: after W has been reallocated in the middle
+             * of the bump, w_end[2m] (the file capacity) is stale, pivot() asks for the same memory again
+             * and the reference loops, growing W by realloc_factor each time until the process dies.  The
+             * restatement reproduces that; three Reallocate returns in a row from the same pivot without
+             * progress are reported as ORC_D5_TRAP instead (the caller re-runs with a W that is large
+             * enough from the start, where results do not depend on the layout: SURVEY 5.2-5). */
+            const lu_int at = obj->lu.rank + obj->lu.rankdef;
+            if (obj->lu.task == ORC_TASK_FACTORIZE_BUMP && obj->lu.addmem_w > 0 && at == stuck_rank) {
+                if (++stuck >= 3) return ORC_D5_TRAP;
+            } else {
+                stuck_rank = at;
+                stuck = 0;
+            }
             if (realloc_obj(obj)) return -9;
             c0ntinue = 1;
             continue;

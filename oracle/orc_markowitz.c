@@ -168,6 +168,7 @@ int orc_factorize_bump(orc_lu *lu)
             orc_list_remove(lu->colcount_flink, lu->colcount_blink, lu->pivot_col);
             lu->pivot_col = -1;
             lu->rankdef++;
+            lu->npivot_kind[5]++; /* test hook */
         } else {
             /* Eliminate pivot. This may require reallocation. */
             ORC_ASSERT(lu->pinv[lu->pivot_row] == -1);

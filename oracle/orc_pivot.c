@@ -41,17 +41,24 @@ int orc_pivot(orc_lu *lu)
     }
 
     /* Branch out implementation of pivot operation. (:84-94) */
-    int status;
-    if (nz_row == 1)
+    int status, kind;
+    if (nz_row == 1) {
+        kind = 0;
         status = pivot_singleton_row(lu);
-    else if (nz_col == 1)
+    } else if (nz_col == 1) {
+        kind = 1;
         status = pivot_singleton_col(lu);
-    else if (nz_col == 2)
+    } else if (nz_col == 2) {
+        kind = 2;
         status = pivot_doubleton_col(lu);
-    else if (nz_col - 1 <= MAXROW_SMALL)
+    } else if (nz_col - 1 <= MAXROW_SMALL) {
+        kind = 3;
         status = pivot_small(lu);
-    else
+    } else {
+        kind = 4;
         status = pivot_any(lu);
+    }
+    if (status == ORC_OK) lu->npivot_kind[kind]++; /* test hook: which path ran */
 
     /* Remove all entries in columns whose maximum entry has dropped below
      * absolute pivot tolerance. (:98-106) */

@@ -155,6 +155,7 @@ void orc_lu_reset(orc_lu *lu)
     lu->time_elim_pivot = 0.0;
     lu->pivot_error = 0.0;
     lu->d3_hits = 0; /* test hook counter, not in the reference */
+    for (int k = 0; k < 6; k++) lu->npivot_kind[k] = 0;
 
     lu->task = ORC_TASK_NONE;
     lu->pivot_row = -1;
@@ -412,6 +413,8 @@ double orc_get_stat(const orc_lu *lu, int key)
     case BLU_STAT_W_MEM: return (double)lu->w_mem;
     case BLU_STAT_L_FLOPS: return (double)lu->l_flops;
     case BLU_STAT_U_FLOPS: return (double)lu->u_flops;
+    case 50: return (double)lu->d3_hits;
+    case 51: case 52: case 53: case 54: case 55: case 56: return (double)lu->npivot_kind[key - 51];
     default: return NAN;
     }
 }

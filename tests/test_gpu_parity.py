@@ -14,6 +14,7 @@ from blu_amd.matrices import CONFIGS, simple_rs
 from tests import util
 
 pytestmark = pytest.mark.gpu
+FSTATS = ("CONDEST_L", "CONDEST_U", "NORM_L", "NORM_U", "NORMEST_L_INV", "NORMEST_U_INV", "ONENORM", "INFNORM")
 
 
 @pytest.fixture(scope="module")
@@ -24,19 +25,19 @@ def blu():
     return blu_amd
 
 
-def _both(blu, oracle, cp, ri, v, params=None, cap=None, block=None, fix_d3=False):
+def _both(blu, oracle, cp, ri, v, params=None, cap=None, block=None, allow_d3=False):
+    """HIP path and oracle on the same input.  The oracle is the FAITHFUL restatement (reference defect D3
+    included) and d3_hits == 0 is asserted on both sides, unless the test says allow_d3 (then, and only if
+    the matrix does hit D3, the 64-bit-mask oracle is the checker: util.oracle_factorize)."""
     m = len(cp) - 1
     g = blu.BLU(m, len(ri))
-    o = oracle.OracleBLU(m, cap if cap else 32 * len(ri) + 1024)
-    if fix_d3:
-        o.set_fix_d3(True)
     for k, val in (params or {}).items():
         g.set_param(k, val)
-        o.set_param(k, val)
     if block:
         g.dbg_set_block(block)
     sg = g.factorize(cp[:-1], cp[1:], ri, v)
-    so = o.factorize(cp[:-1], cp[1:], ri, v)
+    o, so = util.oracle_factorize(oracle, cp, ri, v, params, cap, allow_d3)
+    assert int(g.stat(50)) == o.d3_hits()  # stat 50 = cancellations at position >= 31 (D3 events), device count
     return g, o, sg, so
 
 
@@ -93,7 +94,7 @@ def test_parameters_and_workgroup_sizes(blu, oracle, m, k, bw, tri, offs, seed, 
 ], ids=lambda p: ",".join("%d=%g" % kv for kv in p.items()))
 def test_tolerances_and_search_depth(blu, oracle, params):
     cp, ri, v = oracle.gen_lp_basis(1200, 8, 10, 0.4, 9, 0.6)
-    g, o, sg, so = _both(blu, oracle, cp, ri, v, params, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, params)
     _assert_parity(g, o, sg, so, cp, ri, v)
 
 
@@ -105,7 +106,7 @@ def test_dense_matrix_pivot_any(blu, oracle):
     cp = np.arange(0, m * m + 1, m, dtype=np.uint64)
     ri = np.tile(np.arange(m, dtype=np.uint64), m)
     v = A.T.reshape(-1).copy()
-    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
     assert sg == K.OK
     _assert_parity(g, o, sg, so, cp, ri, v)
     assert g.stat(55) > 0  # pivot_any executed
@@ -132,7 +133,7 @@ def test_long_rows_and_columns(blu, oracle):
             ri.append(i); v.append(x)
         cp[j + 1] = len(ri)
     ri, v = np.array(ri, np.uint64), np.array(v)
-    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v)
     assert sg == K.OK
     _assert_parity(g, o, sg, so, cp, ri, v)
 
@@ -178,7 +179,7 @@ def test_columns_that_sink_below_abstol_are_removed(blu, oracle):
         nri.extend(cols[j][0].tolist()); nv.extend(cols[j][1].tolist())
         ncp[j + 1] = len(nri)
     nri, nv = np.array(nri, np.uint64), np.array(nv)
-    g, o, sg, so = _both(blu, oracle, ncp, nri, nv, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, ncp, nri, nv)
     assert sg == K.WARNING_SINGULAR_MATRIX
     _assert_parity(g, o, sg, so, ncp, nri, nv)
 
@@ -225,10 +226,9 @@ def test_small_initial_capacity_forces_device_side_growth(blu, oracle):
     cp, ri, v = oracle.gen_lp_basis(1500, 8, 16, 0.2, 3, 1.0)
     m = 1500
     g = blu.BLU(m, 16)  # b_nz hint far too small
-    o = oracle.OracleBLU(m, 64 * len(ri))
-    o.set_fix_d3(True)
-    sg, so = g.factorize(cp[:-1], cp[1:], ri, v), o.factorize(cp[:-1], cp[1:], ri, v)
-    assert sg == so == K.OK
+    sg = g.factorize(cp[:-1], cp[1:], ri, v)
+    o, so = util.oracle_factorize(oracle, cp, ri, v, cap=64 * len(ri), allow_d3=True)  # this matrix hits D3 once
+    assert sg == so == K.OK and o.d3_hits() == g.stat(50) == 1
     util.assert_same_factors(g.get_factors(), o.get_factors())
     assert g.stat(K.STAT_DEV_RELAUNCHES) > 1
 
@@ -261,6 +261,64 @@ def test_config_c3_full_size(blu, oracle):
     assert np.abs(B.T @ x - B.T @ xs).max() <= 1e-9 * np.abs(B.T @ xs).max()
 
 
+def test_config_c4_eight_bases_through_the_batch_entry(blu, oracle):
+    """BASELINE.json configs[3]: the 8 independent 50k x 50k bases (seeds 1..8).  On the 8-GPU node each rank
+    factorizes one of them; here all eight go through blu_hip_factorize_batch on the one GPU of the test box
+    (same kernels, one workgroup per basis), and each must equal its own FAITHFUL oracle run, d3_hits == 0."""
+    c = CONFIGS["C4"]
+    mats = [oracle.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"] + b, c["offscale"]) for b in range(8)]
+    hs = [blu.BLU(c["m"], len(ri)) for (cp, ri, v) in mats]
+    sts = blu.blu.factorize_batch(hs, mats=mats)
+    for b, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
+        o, so = util.oracle_factorize(oracle, cp, ri, v, cap=16 * len(ri))  # asserts d3_hits == 0, faithful mask
+        assert sts[b] == so == K.OK, (b, sts[b], so)
+        assert h.stat(50) == 0 and o.d3_hits() == 0
+        f = h.get_factors()
+        util.assert_same_factors(f, o.get_factors())
+        for cn in util.COUNTERS:
+            assert int(h.stat(getattr(K, "STAT_" + cn))) == int(o.stat(getattr(K, "STAT_" + cn))), (b, cn)
+        for cn in FSTATS + ("RESIDUAL_TEST",):
+            assert h.stat(getattr(K, "STAT_" + cn)) == o.stat(getattr(K, "STAT_" + cn)), (b, cn)
+        if b == 0:
+            util.check_factors(cp, ri, v, f)
+    # and one of them alone through the single-basis entry (what a rank of the 8-GPU run executes)
+    cp, ri, v = mats[7]
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, cap=16 * len(ri))
+    assert sg == so == K.OK
+    _assert_parity(g, o, sg, so, cp, ri, v)
+
+
+@pytest.mark.parametrize("no_fast", [False, True], ids=["fast", "general"])
+def test_every_pivot_path_runs(blu, oracle, no_fast):
+    """pivot_singleton_row (pivot.rs:835), pivot_singleton_col (:928), pivot_doubleton_col (:1027), pivot_small
+    (:460), pivot_any (:114) and the empty-column step (factorize_bump.rs:24-33) are each provably taken: the
+    per-path pivot counts of the device equal the oracle's and every one is positive over this set.  With
+    no_fast the general implementations of pivot_small / pivot_singleton_col run instead of the LDS ones."""
+    total = [0] * 6
+    sets = [oracle.gen_lp_basis(*s) for s in ((2000, 3, 8, 0.0, 4, 0.3), (2000, 2, 3, 0.0, 4, 0.3), (2000, 3, 2, 0.5, 4, 0.3))]
+    rng = np.random.default_rng(3)
+    m = 150  # dense: pivot columns with more than 64 off-diagonals -> pivot_any
+    A = rng.standard_normal((m, m)) + 5 * np.eye(m)
+    sets.append((np.arange(0, m * m + 1, m, dtype=np.uint64), np.tile(np.arange(m, dtype=np.uint64), m), A.T.reshape(-1).copy()))
+    cp, ri, v = oracle.gen_lp_basis(900, 7, 8, 0.5, 21, 0.4)  # numerically null columns -> empty-column steps
+    v = v.copy()
+    for j in (3, 77, 500, 899):
+        v[int(cp[j]):int(cp[j + 1])] *= 1e-17
+    sets.append((cp, ri, v))
+    for cp, ri, v in sets:
+        mm = len(cp) - 1
+        g = blu.BLU(mm, len(ri))
+        g.dbg_set_no_fast(no_fast)
+        sg = g.factorize(cp[:-1], cp[1:], ri, v)
+        o, so = util.oracle_factorize(oracle, cp, ri, v)
+        assert sg == so and sg in (K.OK, K.WARNING_SINGULAR_MATRIX)
+        util.assert_same_factors(g.get_factors(), o.get_factors())
+        for kind in range(6):
+            assert g.stat(51 + kind) == o.stat(51 + kind), (mm, kind, g.stat(51 + kind), o.stat(51 + kind))
+            total[kind] += int(g.stat(51 + kind))
+    assert all(t > 0 for t in total), total
+
+
 def test_generators_agree(blu, oracle):
     """The library's generator (bench input) and the oracle's are the same function."""
     for args in ((50, 4, 3, 0.5, 1, 0.3), (3000, 10, 9, 0.5, 7, 0.3)):
@@ -285,9 +343,7 @@ def test_batch_of_independent_bases(blu, oracle):
     for block in (256, 64, 1024):
         sts = blu.blu.factorize_batch(hs, mats=[tuple(m) for m in mats], block=block)
         for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
-            o = oracle.OracleBLU(len(cp) - 1, 64 * len(ri))
-            o.set_fix_d3(True)
-            so = o.factorize(cp[:-1], cp[1:], ri, v)
+            o, so = util.oracle_factorize(oracle, cp, ri, v, cap=64 * len(ri), allow_d3=(k == 7))  # member 7 hits D3 once
             assert sts[k] == so, (k, sts[k], so)
             if so in (K.OK, K.WARNING_SINGULAR_MATRIX):
                 util.assert_same_factors(h.get_factors(), o.get_factors())
@@ -314,9 +370,6 @@ def test_general_paths_only_matches_fast_paths(blu, oracle):
     assert a.stat(54) > 0 and a.stat(K.STAT_NSEARCH_PIVOT) == b.stat(K.STAT_NSEARCH_PIVOT)
 
 
-FSTATS = ("CONDEST_L", "CONDEST_U", "NORM_L", "NORM_U", "NORMEST_L_INV", "NORMEST_U_INV", "ONENORM", "INFNORM")
-
-
 @pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1000, 10, 12, 1.0, 11, 0.2),
                                   (1500, 8, 16, 0.2, 3, 1.0)], ids=lambda s: "m%d" % s[0])
 @pytest.mark.parametrize("block", [1024, 128])
@@ -325,7 +378,7 @@ def test_statistics_tail(blu, oracle, spec, block):
     sum is taken in the reference's order, so all of them -- residual_test, which is pure rounding noise,
     included -- are bit-identical to the oracle."""
     cp, ri, v = oracle.gen_lp_basis(*spec)
-    g, o, sg, so = _both(blu, oracle, cp, ri, v, block=block, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, block=block, allow_d3=(spec[0] == 1500))  # the m=1500 basis hits D3 once
     assert sg == so == K.OK
     for c in FSTATS + ("RESIDUAL_TEST",):
         a, b = g.stat(getattr(K, "STAT_" + c)), o.stat(getattr(K, "STAT_" + c))
@@ -366,7 +419,7 @@ def test_solve_sparse_matches_oracle(blu, oracle, spec, trans):
     values are identical to the reference restatement: bit-exact, including which branch runs."""
     cp, ri, v = oracle.gen_lp_basis(*spec)
     m = spec[0]
-    g, o, sg, so = _both(blu, oracle, cp, ri, v, fix_d3=True)
+    g, o, sg, so = _both(blu, oracle, cp, ri, v, allow_d3=(m == 1500))
     assert sg == so == K.OK
     branches = set()
     for q, nz in enumerate((1, 2, 5, 17, max(1, m // 40), max(1, m // 8), m // 2)):
@@ -450,7 +503,7 @@ def test_solve_dense_identical_to_oracle(blu, oracle, spec):
         if singular:
             for j in (3, m // 3, m - 1):
                 vv[int(cp[j]):int(cp[j + 1])] *= 1e-17
-        g, o, sg, so = _both(blu, oracle, cp, ri, vv, fix_d3=True)
+        g, o, sg, so = _both(blu, oracle, cp, ri, vv, allow_d3=(m == 1500))
         assert sg == so == (K.WARNING_SINGULAR_MATRIX if singular else K.OK)
         for trans in "NT":
             b = rng.standard_normal(m)

@@ -65,3 +65,32 @@ def assert_same_factors(got, want, rtol=RTOL):
 
 def counters(stat):
     return {c: int(stat(getattr(K, "STAT_" + c))) for c in COUNTERS}
+
+
+def oracle_factorize(orc, cp, ri, v, params=None, cap=None, allow_d3=False):
+    """Factorize with the CPU oracle as the REFERENCE restates it (faithful i32 cancellation mask, D3).
+
+    The faithful restatement has no defined result when a cancellation lands at pivot-column position
+    >= 31 (the reference corrupts its row file there), so a first run with the 64-bit mask counts such
+    events (d3_hits).  d3_hits == 0: the faithful oracle is run and returned -- the comparison is with
+    the reference's own semantics.  d3_hits > 0: only callers that say allow_d3=True get the 64-bit-mask
+    run back (the HIP path documents the same deviation); everyone else fails."""
+    m = len(cp) - 1
+    cap = cap if cap else 32 * len(ri) + 1024
+
+    def run(fix):
+        def setup(o):
+            o.set_fix_d3(fix)
+            for k, val in (params or {}).items():
+                o.set_param(k, val)
+        # (factorize_roomy: a capacity too small for the bump would send the faithful restatement into the
+        # reference's endless Reallocate loop, defect D5; it is raised until W never grows inside the bump)
+        return orc.OracleBLU.factorize_roomy(m, cap, cp[:-1], cp[1:], ri, v, setup)
+
+    o, st = run(True)
+    if o.d3_hits() == 0:
+        o, st = run(False)
+        assert o.d3_hits() == 0
+        return o, st
+    assert allow_d3, "reference defect D3 would be hit (%d times): choose another matrix or pass allow_d3" % o.d3_hits()
+    return o, st

@@ -1,16 +1,26 @@
 """Randomized parity run: many small generated bases with random generator and LU parameters and random
 workgroup sizes, HIP path against the CPU oracle -- status, canonical factors, counters, statistics,
 solve_dense and solve_sparse must all be identical.
-   python tools/fuzz_gpu.py [ncases] [seed]        (needs a GPU; the oracle is the checker)
-Round 1: 300 cases (seed 1) all identical.  A 1500-case run (seed 777) ended with the loss of the GPU
-box after ~80 s -- lease fault, no GPU fault recorded, no output returned -- and was not repeated in that
-round (a second lost box closes the GPU for the round); run long sweeps in slices, one process each."""
-import sys, os
+
+   python tools/fuzz_gpu.py [--seed S] [--start A] [--count N] [--log FILE]     (needs a GPU; the oracle is the checker)
+
+Case n of seed S is always the same matrix and parameters, whichever slice [A, A+N) it is run in: the
+cases before A are drawn (and factorized by the oracle alone, whose status decides how many random numbers a
+case consumes) but never touch the GPU.  tests/test_gpu_fuzz.py runs the slices of the sweep, each in a
+fresh child process with a timeout; the tag of a case is written to the log (flushed) BEFORE its first GPU
+call, so a hang or a lost box leaves the parameters that caused it.
+
+Round 1: 300 cases (seed 12345) identical; a 1500-case run (seed 777) ended with the loss of the GPU box.
+Round 2: the same 1500 cases of seed 777 in 15 slices -- see DESIGN.md section 7 for the outcome."""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import blu_amd
-from blu_amd import keys as K
-from oracle import orc
+import numpy as np  # noqa: E402
+
+from blu_amd import keys as K  # noqa: E402
+from oracle import orc  # noqa: E402
 
 INT_KEYS = ("rowperm", "colperm", "l_colptr", "l_rowidx", "u_colptr", "u_rowidx")
 VAL_KEYS = ("l_value", "u_value")
@@ -19,64 +29,119 @@ FSTATS = ("MIN_PIVOT", "MAX_PIVOT", "CONDEST_L", "CONDEST_U", "NORM_L", "NORM_U"
           "ONENORM", "INFNORM", "RESIDUAL_TEST")
 
 
-def one(rng, case):
-    m = int(rng.integers(20, 700))
-    k = int(rng.integers(2, 12))
-    bw = int(rng.integers(1, 40))
-    tri = float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0]))
-    offs = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
-    seed = int(rng.integers(1, 10**6))
-    cp, ri, v = orc.gen_lp_basis(m, k, bw, tri, seed, offs)
+def draw(rng):
+    """The generator / LU parameters of one case (consumes the random stream exactly as round 1's tool did)."""
+    c = {}
+    c["m"] = m = int(rng.integers(20, 700))
+    c["k"] = int(rng.integers(2, 12))
+    c["bw"] = int(rng.integers(1, 40))
+    c["tri"] = float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0]))
+    c["offs"] = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
+    c["seed"] = int(rng.integers(1, 10**6))
+    cp, ri, v = orc.gen_lp_basis(m, c["k"], c["bw"], c["tri"], c["seed"], c["offs"])
     v = v.copy()
+    c["null_cols"] = []
     if rng.random() < 0.25:  # some numerically null columns -> rank deficiency, remove_col
         for j in rng.choice(m, int(rng.integers(1, 4)), replace=False):
             v[int(cp[j]):int(cp[j + 1])] *= 1e-17
-    params = {K.PARAM_NZBIAS: int(rng.choice([1, -1, 0, 3])), K.PARAM_SEARCH_ROWS: int(rng.random() < 0.3),
-              K.PARAM_MAXSEARCH: int(rng.choice([1, 2, 3, 4, 7])), K.PARAM_RELTOL: float(rng.choice([0.1, 0.01, 0.5, 1.0])),
-              K.PARAM_PAD: int(rng.choice([4, 0, 1, 9])), K.PARAM_STRETCH: float(rng.choice([0.3, 0.0, 1.0])),
-              K.PARAM_SPARSE_THRES: float(rng.choice([0.05, 0.0, 0.5, 1.0]))}
-    block = int(rng.choice([64, 128, 256, 512, 1024]))
-    hint = len(ri) if rng.random() < 0.7 else max(1, len(ri) // int(rng.integers(2, 30)))  # small: device-side growth
-    g = blu_amd.BLU(m, hint)
-    o = orc.OracleBLU(m, 64 * len(ri) + 1024)
-    o.set_fix_d3(True)
-    for key, val in params.items():
-        g.set_param(key, val)
-        o.set_param(key, val)
-    g.dbg_set_block(block)
-    tag = "case %d: m=%d k=%d bw=%d tri=%g offs=%g seed=%d block=%d hint=%d params=%s" % (case, m, k, bw, tri, offs, seed, block, hint, params)
-    sg = g.factorize(cp[:-1], cp[1:], ri, v)
-    so = o.factorize(cp[:-1], cp[1:], ri, v)
-    assert sg == so, (tag, sg, so)
-    if sg not in (K.OK, K.WARNING_SINGULAR_MATRIX):
-        return tag
-    fg, fo = g.get_factors(), o.get_factors()
-    for key in INT_KEYS + VAL_KEYS:
-        assert np.array_equal(fg[key], fo[key]), (tag, key)
-    for c in COUNTERS + FSTATS:
-        a, b = g.stat(getattr(K, "STAT_" + c)), o.stat(getattr(K, "STAT_" + c))
-        assert a == b or (a != a and b != b), (tag, c, a, b)
+            c["null_cols"].append(int(j))
+    c["params"] = {K.PARAM_NZBIAS: int(rng.choice([1, -1, 0, 3])), K.PARAM_SEARCH_ROWS: int(rng.random() < 0.3),
+                   K.PARAM_MAXSEARCH: int(rng.choice([1, 2, 3, 4, 7])), K.PARAM_RELTOL: float(rng.choice([0.1, 0.01, 0.5, 1.0])),
+                   K.PARAM_PAD: int(rng.choice([4, 0, 1, 9])), K.PARAM_STRETCH: float(rng.choice([0.3, 0.0, 1.0])),
+                   K.PARAM_SPARSE_THRES: float(rng.choice([0.05, 0.0, 0.5, 1.0]))}
+    c["block"] = int(rng.choice([64, 128, 256, 512, 1024]))
+    c["hint"] = len(ri) if rng.random() < 0.7 else max(1, len(ri) // int(rng.integers(2, 30)))  # small: device-side growth
+    return c, (cp, ri, v)
+
+
+def draw_solves(rng, m):
+    out = []
     for trans in "NT":
         b = rng.standard_normal(m)
-        assert np.array_equal(g.solve_dense(b, trans), o.solve_dense(b, trans), equal_nan=True), (tag, "solve_dense", trans)
         nz = int(rng.integers(1, max(2, m // 3)))
         ir = rng.choice(m, nz, replace=False)
         xr = rng.standard_normal(nz)
-        st_o, il, lhs = o.solve_sparse(ir, xr, trans)
-        assert g.solve_sparse(ir, xr, trans) == st_o == K.OK, (tag, "solve_sparse status")
-        assert np.array_equal(g.ilhs[:g.nzlhs], il) and np.array_equal(g.lhs, lhs, equal_nan=True), (tag, "solve_sparse", trans)
+        out.append((trans, b, ir, xr))
+    return out
+
+
+def tag_of(case, c):
+    return "case %d: m=%d k=%d bw=%d tri=%g offs=%g seed=%d null=%s block=%d hint=%d params=%s" % (
+        case, c["m"], c["k"], c["bw"], c["tri"], c["offs"], c["seed"], c["null_cols"], c["block"], c["hint"], c["params"])
+
+
+def oracle_of(c, mat):
+    cp, ri, v = mat
+
+    def setup(o):
+        o.set_fix_d3(True)  # random matrices do hit D3 now and then; d3_hits is compared with the device's count
+        for key, val in c["params"].items():
+            o.set_param(key, val)
+    # factorize_roomy: with too small a capacity the faithful restatement enters the reference's endless
+    # Reallocate loop (defect D5) and eats the host's memory -- that, in the ORACLE, is what took the GPU box
+    # down in round 1's 1500-case run (case 619 of seed 777); the capacity is raised until W never grows
+    # inside the bump.
+    return orc.OracleBLU.factorize_roomy(c["m"], 64 * len(ri) + 1024, cp[:-1], cp[1:], ri, v, setup)
+
+
+def run_case(blu_amd, case, c, mat, o, so, solves, log):
+    cp, ri, v = mat
+    tag = tag_of(case, c)
+    log.write("start " + tag + "\n")
+    log.flush()
+    os.fsync(log.fileno())
+    g = blu_amd.BLU(c["m"], c["hint"])
+    for key, val in c["params"].items():
+        g.set_param(key, val)
+    g.dbg_set_block(c["block"])
+    sg = g.factorize(cp[:-1], cp[1:], ri, v)
+    assert sg == so, (tag, sg, so)
+    if sg in (K.OK, K.WARNING_SINGULAR_MATRIX):
+        fg, fo = g.get_factors(), o.get_factors()
+        for key in INT_KEYS + VAL_KEYS:
+            assert np.array_equal(fg[key], fo[key]), (tag, key)
+        for cn in COUNTERS + FSTATS:
+            a, b = g.stat(getattr(K, "STAT_" + cn)), o.stat(getattr(K, "STAT_" + cn))
+            assert a == b or (a != a and b != b), (tag, cn, a, b)
+        assert int(g.stat(50)) == o.d3_hits(), (tag, "d3_hits")
+        for kind in range(6):
+            assert g.stat(51 + kind) == o.stat(51 + kind), (tag, "pivot kind", kind)
+        for trans, b, ir, xr in solves:
+            assert np.array_equal(g.solve_dense(b, trans), o.solve_dense(b, trans), equal_nan=True), (tag, "solve_dense", trans)
+            st_o, il, lhs = o.solve_sparse(ir, xr, trans)
+            assert g.solve_sparse(ir, xr, trans) == st_o == K.OK, (tag, "solve_sparse status")
+            assert np.array_equal(g.ilhs[:g.nzlhs], il) and np.array_equal(g.lhs, lhs, equal_nan=True), (tag, "solve_sparse", trans)
     g.close()
-    return tag
+    log.write("done %d\n" % case)
+    return [int(o.stat(51 + k)) for k in range(6)], o.d3_hits()
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-    for case in range(n):
-        tag = one(rng, case)
-        if case % 25 == 0:
-            print("ok", tag, flush=True)
-    print("all %d cases identical" % n)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--start", type=int, default=0)
+    ap.add_argument("--count", type=int, default=200)
+    ap.add_argument("--log", default="")
+    a = ap.parse_args()
+    log = open(a.log, "w") if a.log else sys.stdout
+    rng = np.random.default_rng(a.seed)
+    blu_amd = None
+    kinds, d3 = [0] * 6, 0
+    for case in range(a.start + a.count):
+        c, mat = draw(rng)
+        o, so = oracle_of(c, mat)
+        solves = draw_solves(rng, c["m"]) if so in (K.OK, K.WARNING_SINGULAR_MATRIX) else []
+        if case < a.start:
+            continue
+        if blu_amd is None:
+            import blu_amd  # first GPU use only when the slice begins
+        kk, dd = run_case(blu_amd, case, c, mat, o, so, solves, log)
+        kinds = [x + y for x, y in zip(kinds, kk)]
+        d3 += dd
+    log.write("all %d cases of seed %d from %d identical; pivots by path %s, d3 events %d\n" % (a.count, a.seed, a.start, kinds, d3))
+    log.flush()
+    if log is not sys.stdout:
+        print("all %d cases of seed %d from %d identical; pivots by path %s, d3 events %d" % (a.count, a.seed, a.start, kinds, d3))
 
 
 if __name__ == "__main__":
