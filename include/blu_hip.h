@@ -85,10 +85,18 @@ enum blu_stat {
     BLU_STAT_W_MEM = 32,
     BLU_STAT_L_FLOPS = 33,       /* lu.l_flops, accumulated by solve_sparse (lu/solve_sparse.rs:356) */
     BLU_STAT_U_FLOPS = 34,       /* lu.u_flops (:357) */
+    BLU_STAT_NFORREST = 35,      /* lu.nforrest: Forrest-Tomlin updates since the last factorize (lu.rs:92) */
+    BLU_STAT_PIVOT_ERROR = 36,   /* lu.pivot_error of the last update (update.rs:942) */
+    BLU_STAT_R_NZ = 37,          /* lu.r_nz: nonzeros in the row eta file */
+    BLU_STAT_R_FLOPS = 38,       /* lu.r_flops (lu/solve_sparse.rs:358) */
+    BLU_STAT_MAX_ETA = 39,       /* lu.max_eta */
     /* device-side extras (no reference counterpart) */
     BLU_STAT_DEV_TIME_PIVOT_LOOP = 40,  /* seconds, hipEvent, last factorize */
     BLU_STAT_DEV_TIME_TOTAL = 41,       /* seconds, hipEvent, all kernels of last factorize */
-    BLU_STAT_DEV_RELAUNCHES = 42        /* pivot-loop kernel launches of last factorize */
+    BLU_STAT_DEV_RELAUNCHES = 42,       /* pivot-loop kernel launches of last factorize */
+    BLU_STAT_NSYMPERM_TOTAL = 48,       /* lu.nsymperm_total: updates done by a symmetric permutation alone */
+    BLU_STAT_NFORREST_TOTAL = 49,       /* lu.nforrest_total */
+    BLU_STAT_DEV_NUNSYMPERM_TOTAL = 59  /* updates done by an unsymmetric permutation (update.rs:794-814); no getter in the reference */
 };
 
 typedef struct blu_hip blu_hip; /* opaque: owns all device + host state (= struct LU + struct BLU) */

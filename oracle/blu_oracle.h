@@ -114,6 +114,7 @@ typedef struct orc_lu {
                          panics can still be compared with the HIP path */
     lu_int d3_hits;   /* cancellations recorded at pivot-column position >= 32:
                          0 means the faithful and the fixed runs are identical */
+    lu_int nunsymperm_total; /* updates done by an unsymmetric permutation (test hook; no counter in the reference) */
     lu_int npivot_kind[6]; /* pivots taken per path: 0 singleton row, 1 singleton col, 2 doubleton col,
                               3 small, 4 any, 5 empty column (factorize_bump.rs:24-33) */
     lu_int stop_after_pivots; /* <0: off; else factorize_bump returns
@@ -144,6 +145,13 @@ int orc_blu_solve_sparse(orc_blu *obj, lu_int nzrhs, const uint64_t *irhs, const
 lu_int orc_blu_nzlhs(const orc_blu *obj);
 void orc_blu_get_lhs(const orc_blu *obj, lu_int *ilhs, double *lhs);
 orc_lu *orc_blu_lu(orc_blu *obj);
+/* BLU::solve_for_update (blu.rs:257) / BLU::update (blu.rs:319): the INTENDED Forrest-Tomlin algorithm, NOT
+ * reference-pinned (the reference is defective there: orc_update.c lists the repairs). */
+int orc_blu_solve_for_update(orc_blu *obj, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, char trans, int want_solution);
+int orc_blu_update(orc_blu *obj, double xtbl);
+int orc_solve_for_update(orc_lu *lu, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, lu_int *p_nzlhs,
+                         lu_int *ilhs, double *lhs, char trans);  /* solve_for_update.rs:73 */
+int orc_update(orc_lu *lu, double xtbl);                          /* update.rs:49 */
 
 /* --- procedural API (src/factorize.rs, get_factors.rs, solve_dense.rs) --- */
 int orc_factorize(orc_lu *lu, const uint64_t *b_begin, const uint64_t *b_end,

@@ -44,6 +44,8 @@ def lib():
         L.orc_blu_get_factors.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.orc_blu_solve_dense.argtypes = [C.c_void_p, _f64p, _f64p, C.c_char]
         L.orc_blu_solve_sparse.argtypes = [C.c_void_p, C.c_int64, _u64p, _f64p, C.c_char]
+        L.orc_blu_solve_for_update.argtypes = [C.c_void_p, C.c_int64, _u64p, C.c_void_p, C.c_char, C.c_int]
+        L.orc_blu_update.argtypes = [C.c_void_p, C.c_double]
         L.orc_blu_nzlhs.restype = C.c_int64
         L.orc_blu_nzlhs.argtypes = [C.c_void_p]
         L.orc_blu_get_lhs.argtypes = [C.c_void_p, C.c_void_p, _f64p]
@@ -174,6 +176,25 @@ class OracleBLU:
         lhs = np.zeros(self.m)
         lib().orc_blu_get_lhs(self._h, il.ctypes.data, _p(lhs, _f64p))
         return st, il[:nz], lhs
+
+    def solve_for_update(self, irhs, xrhs=None, trans="N", want_solution=True):
+        """BLU::solve_for_update (blu.rs:257), INTENDED algorithm (oracle/orc_update.c; not reference-pinned).
+        Returns (status, ilhs, lhs) like solve_sparse; ilhs/lhs are None when no solution was wanted."""
+        ir = np.ascontiguousarray(irhs, dtype=np.uint64)
+        xr = None if xrhs is None else np.ascontiguousarray(xrhs, dtype=np.float64)
+        st = lib().orc_blu_solve_for_update(self._h, len(ir), _p(ir, _u64p), None if xr is None else xr.ctypes.data,
+                                            trans.encode()[0:1], int(bool(want_solution)))
+        if st != OK or not want_solution:
+            return st, None, None
+        nz = int(lib().orc_blu_nzlhs(self._h))
+        il = np.zeros(max(1, nz), np.int64)
+        lhs = np.zeros(self.m)
+        lib().orc_blu_get_lhs(self._h, il.ctypes.data, _p(lhs, _f64p))
+        return st, il[:nz], lhs
+
+    def update(self, xtbl):
+        """BLU::update (blu.rs:319), INTENDED algorithm (oracle/orc_update.c)."""
+        return lib().orc_blu_update(self._h, float(xtbl))
 
     # ---- debug hooks (not in the reference) --------------------------------
     def set_stop(self, npivots):

@@ -196,6 +196,72 @@ int orc_blu_factorize(orc_blu *obj, const uint64_t *b_begin, const uint64_t *b_e
     return result;
 }
 
+/* solve_for_update -- src/solve_for_update.rs:73-119 (argument checks), then lu::solve_for_update.
+ * The update path is the INTENDED algorithm, not reference-pinned: see orc_update.c. */
+int orc_solve_for_update(orc_lu *lu, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, lu_int *p_nzlhs,
+                         lu_int *ilhs, double *lhs, char trans)
+{
+    const int tr = trans == 't' || trans == 'T';
+    if (!tr && !xrhs) return ORC_ERROR_ARGUMENT_MISSING;
+    if (lu->nupdate < 0) return ORC_ERROR_INVALID_CALL;
+    if (lu->nforrest == lu->m) return ORC_ERROR_MAXIMUM_UPDATES;
+    int ok;
+    if (tr) {
+        ok = irhs[0] < (uint64_t)lu->m;
+    } else {
+        ok = nzrhs >= 0 && nzrhs <= lu->m;
+        for (lu_int n = 0; ok && n < nzrhs; n++) ok = ok && irhs[n] < (uint64_t)lu->m;
+    }
+    if (!ok) return ORC_ERROR_INVALID_ARGUMENT;
+    const lu_int cnt = tr ? 1 : nzrhs;
+    lu_int *ir = (lu_int *)malloc((size_t)(cnt > 0 ? cnt : 1) * sizeof(lu_int));
+    for (lu_int n = 0; n < cnt; n++) ir[n] = (lu_int)irhs[n];
+    int st = orc_lu_solve_for_update(lu, nzrhs, ir, xrhs, p_nzlhs, ilhs, lhs, trans);
+    free(ir);
+    return st;
+}
+
+/* update -- src/update.rs:49-55 */
+int orc_update(orc_lu *lu, double xtbl)
+{
+    if (lu->nupdate < 0 || lu->ftran_for_update < 0 || lu->btran_for_update < 0) return ORC_ERROR_INVALID_CALL;
+    return orc_lu_update(lu, xtbl);
+}
+
+/* BLU::solve_for_update -- blu.rs:257-288.  FIX D11: the solution is computed only when it is wanted. */
+int orc_blu_solve_for_update(orc_blu *obj, lu_int nzrhs, const uint64_t *irhs, const double *xrhs, char trans, int want_solution)
+{
+    int result;
+    orc_clear_lhs(obj);
+    for (;;) {
+        lu_int nzlhs = 0;
+        result = want_solution ? orc_solve_for_update(&obj->lu, nzrhs, irhs, xrhs, &nzlhs, obj->ilhs, obj->lhs, trans)
+                               : orc_solve_for_update(&obj->lu, nzrhs, irhs, xrhs, NULL, NULL, NULL, trans);
+        if (want_solution) obj->nzlhs = nzlhs;
+        if (result == ORC_REALLOCATE) {
+            if (realloc_obj(obj)) return -9;
+            continue;
+        }
+        break;
+    }
+    return result;
+}
+
+/* BLU::update -- blu.rs:319-335 */
+int orc_blu_update(orc_blu *obj, double xtbl)
+{
+    int result;
+    for (;;) {
+        result = orc_update(&obj->lu, xtbl);
+        if (result == ORC_REALLOCATE) {
+            if (realloc_obj(obj)) return -9;
+            continue;
+        }
+        break;
+    }
+    return result;
+}
+
 /* BLU::get_factors -- blu.rs:139-160 */
 int orc_blu_get_factors(orc_blu *obj, lu_int *rowperm, lu_int *colperm,
                         lu_int *l_colptr, lu_int *l_rowidx, double *l_value,

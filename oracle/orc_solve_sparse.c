@@ -70,7 +70,7 @@ static lu_int dfs_begin(lu_int i, const lu_int *begin, const lu_int *index, lu_i
 }
 
 /* dfs -- dfs.rs:25-46 */
-static lu_int orc_dfs(lu_int i, const lu_int *begin, const lu_int *end, const lu_int *index, lu_int top,
+lu_int orc_dfs(lu_int i, const lu_int *begin, const lu_int *end, const lu_int *index, lu_int top,
                       lu_int *xi, double *pstack, lu_int *marked, lu_int M)
 {
     if (marked[i] == M) return top;
@@ -79,7 +79,7 @@ static lu_int orc_dfs(lu_int i, const lu_int *begin, const lu_int *end, const lu
 }
 
 /* solve_symbolic -- solve_symbolic.rs:19-40 */
-static lu_int orc_solve_symbolic(lu_int m, const lu_int *begin, const lu_int *end, const lu_int *index,
+lu_int orc_solve_symbolic(lu_int m, const lu_int *begin, const lu_int *end, const lu_int *index,
                                  lu_int nrhs, const lu_int *irhs, lu_int *ilhs, double *pstack,
                                  lu_int *marked, lu_int M)
 {
@@ -91,7 +91,7 @@ static lu_int orc_solve_symbolic(lu_int m, const lu_int *begin, const lu_int *en
 
 /* solve_triangular -- solve_triangular.rs:27-136.  The four variants of the reference differ only in
  * how a column ends (end[] or a negative index) and in the division by the pivot. */
-static lu_int orc_solve_triangular(lu_int nz_symb, const lu_int *pattern_symb, const lu_int *begin,
+lu_int orc_solve_triangular(lu_int nz_symb, const lu_int *pattern_symb, const lu_int *begin,
                                    const lu_int *end, const lu_int *index, const double *value,
                                    const double *pivot, double droptol, double *lhs, lu_int *pattern,
                                    lu_int *flops)
@@ -296,7 +296,7 @@ int orc_solve_sparse(orc_lu *lu, lu_int nzrhs, const uint64_t *irhs, const doubl
 }
 
 /* lu_clear_lhs -- blu.rs:380-395 */
-static void orc_clear_lhs(orc_blu *obj)
+void orc_clear_lhs(orc_blu *obj)
 {
     const lu_int m = obj->lu.m;
     const lu_int nzsparse = (lu_int)(obj->lu.sparse_thres * (double)m);

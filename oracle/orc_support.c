@@ -413,6 +413,14 @@ double orc_get_stat(const orc_lu *lu, int key)
     case BLU_STAT_W_MEM: return (double)lu->w_mem;
     case BLU_STAT_L_FLOPS: return (double)lu->l_flops;
     case BLU_STAT_U_FLOPS: return (double)lu->u_flops;
+    case BLU_STAT_NFORREST: return (double)lu->nforrest;
+    case BLU_STAT_PIVOT_ERROR: return lu->pivot_error;
+    case BLU_STAT_R_NZ: return (double)lu->r_nz;
+    case BLU_STAT_R_FLOPS: return (double)lu->r_flops;
+    case BLU_STAT_MAX_ETA: return lu->max_eta;
+    case BLU_STAT_NSYMPERM_TOTAL: return (double)lu->nsymperm_total;
+    case BLU_STAT_NFORREST_TOTAL: return (double)lu->nforrest_total;
+    case BLU_STAT_DEV_NUNSYMPERM_TOTAL: return (double)lu->nunsymperm_total;
     case 50: return (double)lu->d3_hits;
     case 51: case 52: case 53: case 54: case 55: case 56: return (double)lu->npivot_kind[key - 51];
     default: return NAN;
