@@ -36,6 +36,7 @@ EXPORTS = [
     "blu_hip_new", "blu_hip_free", "blu_hip_set_param", "blu_hip_get_param", "blu_hip_get_stat",
     "blu_hip_factorize", "blu_hip_factorize_device", "blu_hip_get_factors", "blu_hip_solve_dense",
     "blu_hip_factorize_batch", "blu_hip_version", "blu_hip_device_count", "blu_hip_last_error",
+    "blu_hip_solve_sparse", "blu_hip_solve_for_update", "blu_hip_update", "blu_hip_set_skip_stats", "blu_hip_gen_lp_basis",
 ]
 
 
@@ -74,6 +75,8 @@ def lib():
         L.blu_hip_get_factors.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.blu_hip_solve_dense.argtypes = [C.c_void_p, _f64p, _f64p, C.c_char]
         L.blu_hip_solve_sparse.argtypes = [C.c_void_p, C.c_int64, _u64p, _f64p, C.c_void_p, C.c_void_p, _f64p, C.c_char]
+        L.blu_hip_solve_for_update.argtypes = [C.c_void_p, C.c_int64, _u64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char]
+        L.blu_hip_update.argtypes = [C.c_void_p, C.c_double]
         L.blu_hip_version.restype = C.c_char_p
         L.blu_hip_last_error.restype = C.c_char_p
         L.blu_hip_last_error.argtypes = [C.c_void_p]
@@ -254,6 +257,47 @@ class BLU:
         if st == K.OK:
             self.nzlhs = int(nz.value)
         elif st in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):
+            raise BluError(st, self.last_error())
+        return st
+
+    def _clear_lhs(self):
+        m = self.m
+        if self.lhs is None:
+            self.lhs = np.zeros(m)
+            self.ilhs = np.zeros(max(1, m), np.int64)
+            self.nzlhs = 0
+        if self.nzlhs:  # lu_clear_lhs, blu.rs:380-395
+            if self.nzlhs <= int(self.get_param(K.PARAM_SPARSE_THRES) * m):
+                self.lhs[self.ilhs[:self.nzlhs]] = 0.0
+            else:
+                self.lhs[:] = 0.0
+            self.nzlhs = 0
+
+    # --- BLU::solve_for_update (blu.rs:257) --------------------------------------------------------
+    def solve_for_update(self, irhs, xrhs=None, trans="N", want_solution=True):
+        """Prepare an update.  trans 'T': irhs[0] is the column to be replaced; otherwise irhs/xrhs is the column
+        to be inserted.  With want_solution the solution of the system is left in self.lhs / self.ilhs[0..nzlhs)
+        as by solve_sparse.  Returns the status."""
+        self._clear_lhs()
+        ir = np.ascontiguousarray(irhs, dtype=np.uint64)
+        xr = None if xrhs is None else np.ascontiguousarray(xrhs, dtype=np.float64)
+        nz = C.c_int64(0)
+        if want_solution:
+            st = lib().blu_hip_solve_for_update(self._h, len(ir), _p(ir, _u64p), None if xr is None else xr.ctypes.data,
+                                                C.addressof(nz), self.ilhs.ctypes.data, self.lhs.ctypes.data, trans.encode()[0:1])
+        else:
+            st = lib().blu_hip_solve_for_update(self._h, len(ir), _p(ir, _u64p), None if xr is None else xr.ctypes.data,
+                                                None, None, None, trans.encode()[0:1])
+        if st == K.OK and want_solution:
+            self.nzlhs = int(nz.value)
+        elif st in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):
+            raise BluError(st, self.last_error())
+        return st
+
+    # --- BLU::update (blu.rs:319) ------------------------------------------------------------------
+    def update(self, xtbl):
+        st = lib().blu_hip_update(self._h, float(xtbl))
+        if st in (K.ERROR_DEVICE, K.ERROR_OUT_OF_MEMORY):
             raise BluError(st, self.last_error())
         return st
 

@@ -22,6 +22,7 @@
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"
 #include "k_stats.hip"
+#include "k_update.hip"
 
 #define BLU_STOPPED_STATUS 100 /* debug stepping only */
 
@@ -60,6 +61,11 @@ struct blu_hip {
     int *d_irhs;
     double *d_xrhs;
     int64_t rhs_cap;
+    // update path (k_update.hip): mutable copies of U, maps, pivot sequence, row etas; built at the first solve_for_update
+    UpdWs uw;
+    UpdState ust;           // last downloaded state
+    int64_t upd_alloc_m;    // m the fixed-size arrays of uw were allocated for (-1: none)
+    int64_t upd_for_nfact;  // nfactorize uw was built for (-1: none)
     int64_t sp_l_flops, sp_u_flops; // lu.l_flops / lu.u_flops
     int sp_branch;                  // 1 sparse, 2 sequential: branch of the last solve_sparse (diagnostic)
     // timing
@@ -112,6 +118,7 @@ template <class T> static bool dgrow(blu_hip *h, T **p, size_t keep, size_t n)
 
 static const int64_t kIntMax = 0x7ffffff0;
 
+static void free_upd(blu_hip *h);
 static void free_all(blu_hip *h)
 {
     DevLU &D = h->D;
@@ -125,6 +132,7 @@ static void free_all(blu_hip *h)
     dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
     dfree(W.xval); dfree(W.out); dfree(W.lt_ptr); dfree(W.lt_idx); dfree(W.lt_val); dfree(W.lt_cur);
     dfree(h->d_irhs); dfree(h->d_xrhs);
+    free_upd(h);
     // everything else lives in the slab
     dfree(h->slab);
 }
@@ -198,6 +206,10 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->rhs_cap = 0;
     h->sp_l_flops = h->sp_u_flops = 0;
     h->sp_branch = 0;
+    memset(&h->uw, 0, sizeof(UpdWs));
+    memset(&h->ust, 0, sizeof(UpdState));
+    h->upd_alloc_m = -1;
+    h->upd_for_nfact = -1;
     h->stop_at = -1;
     h->block_threads = 1024;
     h->no_fast = 0;
@@ -349,6 +361,14 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_W_MEM: return (double)h->D.carena_cap + (double)h->D.rarena_cap;
     case BLU_STAT_L_FLOPS: return (double)h->sp_l_flops;
     case BLU_STAT_U_FLOPS: return (double)h->sp_u_flops;
+    case BLU_STAT_NFORREST: return h->upd_for_nfact == h->nfactorize ? (double)h->ust.nforrest : 0.0;
+    case BLU_STAT_PIVOT_ERROR: return h->ust.pivot_error;
+    case BLU_STAT_R_NZ: return h->upd_for_nfact == h->nfactorize ? (double)h->ust.r_nz : 0.0;
+    case BLU_STAT_R_FLOPS: return (double)h->ust.r_flops;
+    case BLU_STAT_MAX_ETA: return h->ust.max_eta;
+    case BLU_STAT_NSYMPERM_TOTAL: return (double)h->ust.nsymperm_total;
+    case BLU_STAT_NFORREST_TOTAL: return (double)h->ust.nforrest_total;
+    case BLU_STAT_DEV_NUNSYMPERM_TOTAL: return (double)h->ust.nunsymperm_total;
     case 44: case 45: case 46: case 47: return h->t_phase[key - 44]; // device seconds of k_prep / k_setup / k_finish / k_stats
     case 43: return (double)h->sp_branch; // branch of the last solve_sparse: 1 sparse, 2 sequential
     case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;
@@ -530,7 +550,9 @@ static int ensure_lt(blu_hip *h)
     return BLU_OK;
 }
 
-// BLU::solve_dense -- src/blu.rs:182, lu/solve_dense.rs:7-120 (fresh factorization: nforrest == 0)
+#include "blu_update.inc"
+
+// BLU::solve_dense -- src/blu.rs:182, lu/solve_dense.rs:7-120
 extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, char trans)
 {
     if (!h) return BLU_ERROR_ARGUMENT_MISSING;
@@ -541,6 +563,12 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     const size_t M = (size_t)h->m;
     if (!hip_ok(h, hipMemcpy(h->d_rhs, rhs, M * 8, hipMemcpyHostToDevice), "h2d rhs")) return BLU_ERROR_DEVICE;
     const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
+    if (h->nupdate > 0) { // updated factorization: mutable U, row etas, pivot sequence (k_update.hip)
+        const int st = solve_dense_updated(h, tr);
+        if (st != BLU_OK) return st;
+        if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
+        return BLU_OK;
+    }
     if (!tr) { // the forward L solve takes row dots (solve_dense.rs:79-86)
         const int st = ensure_lt(h);
         if (st != BLU_OK) return st;
@@ -577,6 +605,7 @@ extern "C" int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *i
         h->marker = 0;
     }
     const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
+    if (h->nupdate > 0) return solve_sparse_updated(h, nzrhs, irhs, xrhs, p_nzlhs, ilhs, lhs, tr);
     if (tr) { // the transposed system ends with L': row-wise L
         const int st = ensure_lt(h);
         if (st != BLU_OK) return st;

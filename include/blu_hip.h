@@ -149,10 +149,35 @@ int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, char trans);
  * depth-first searches produce, or pivot order when the sequential branch runs; parameters
  * BLU_PARAM_SPARSE_THRES and BLU_PARAM_DROPTOL decide as in the reference).  ilhs must have room for m.
  * Returns BLU_ERROR_INVALID_CALL without a valid factorization, BLU_ERROR_INVALID_ARGUMENT for
- * nzrhs < 0, nzrhs > m or an index out of range.  Fresh factorizations only (no Forrest-Tomlin
- * updates exist on this path yet). */
+ * nzrhs < 0, nzrhs > m or an index out of range.  Works on fresh and on updated factorizations. */
 int blu_hip_solve_sparse(blu_hip *h, int64_t nzrhs, const uint64_t *irhs, const double *xrhs,
                          int64_t *p_nzlhs, int64_t *ilhs, double *lhs, char trans);
+
+/* solve_for_update -- src/solve_for_update.rs:73-119 (BLU::solve_for_update, src/blu.rs:257-288, keeps the
+ * outputs inside the object), lu/solve_for_update.rs:12-455.  Prepares an update of the factorization:
+ *   trans 't'/'T': the column to be REPLACED is irhs[0] (nzrhs, xrhs and irhs[1..] are not read); computes and
+ *                  stores the row eta (partial solve with U').
+ *   otherwise:     irhs[0..nzrhs) / xrhs[0..nzrhs) (no duplicates) is the column to be INSERTED; computes and
+ *                  stores the spike (solve with L and the row etas).
+ * If p_nzlhs, ilhs and lhs are all non-NULL the solution of the system is completed and returned as by
+ * blu_hip_solve_sparse (lhs all zero on entry); otherwise only the update is prepared.  Returns
+ * BLU_ERROR_INVALID_CALL without a valid factorization, BLU_ERROR_MAXIMUM_UPDATES after m Forrest-Tomlin
+ * updates, BLU_ERROR_INVALID_ARGUMENT for indices out of range, BLU_ERROR_ARGUMENT_MISSING for a forward
+ * solve without xrhs.  Status::Reallocate is handled inside, as BLU::solve_for_update does.
+ * The reference's own code is defective on this path; what is implemented is the
+ * algorithm it documents (blu_amd/csrc/k_update.hip, repairs listed in oracle/orc_update.c). */
+int blu_hip_solve_for_update(blu_hip *h, int64_t nzrhs, const uint64_t *irhs, const double *xrhs,
+                             int64_t *p_nzlhs, int64_t *ilhs, double *lhs, char trans);
+
+/* update -- src/update.rs:49-55 (BLU::update, src/blu.rs:319-335), lu/update.rs:388-959: replaces the column
+ * named by the last transposed blu_hip_solve_for_update by the column given to the last forward one
+ * (Forrest-Tomlin update, or a pure permutation update when the spiked U is still permuted triangular).
+ * xtbl = element jpivot of the forward solution (stability monitor only: BLU_STAT_PIVOT_ERROR).  Returns
+ * BLU_ERROR_INVALID_CALL unless both solves were done, BLU_ERROR_SINGULAR_UPDATE if the new pivot is zero or
+ * below abstol (the old factorization stays valid).  Afterwards BLU_STAT_NUPDATE is one higher,
+ * blu_hip_get_factors answers BLU_ERROR_INVALID_CALL (get_factors.rs:59) and the solves work on the updated
+ * factorization. */
+int blu_hip_update(blu_hip *h, double xtbl);
 
 /* Batch extension (no reference counterpart; the reference's only parallel
  * axis is independent BLU objects).  Factorizes n handles that

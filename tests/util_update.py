@@ -75,17 +75,44 @@ def backward_error(A, x, b):
     return np.abs(A @ x - b).max() / max(den, 1e-300)
 
 
-def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max=False, tol_xtbl=1e-3, pair_row=None):
+def _sfu(h, irhs, xrhs, trans):
+    """solve_for_update on either kind of object -> (status, ilhs, lhs)."""
+    out = h.solve_for_update(irhs, xrhs, trans)
+    if isinstance(out, tuple):
+        return out
+    return (out, h.ilhs[:h.nzlhs].copy(), h.lhs.copy()) if out == K.OK else (out, None, None)
+
+
+def _ss(h, irhs, xrhs, trans):
+    out = h.solve_sparse(irhs, xrhs, trans)
+    if isinstance(out, tuple):
+        return out
+    return (out, h.ilhs[:h.nzlhs].copy(), h.lhs.copy()) if out == K.OK else (out, None, None)
+
+
+def _same(a, b, what):
+    """(status, pattern, values) of the device and of its CPU twin: identical, bit for bit, pattern order included."""
+    assert a[0] == b[0], (what, a[0], b[0])
+    if a[0] == K.OK and a[1] is not None:
+        assert np.array_equal(a[1], b[1]), (what, "pattern")
+        assert np.array_equal(a[2], b[2]), (what, "values", np.abs(a[2] - b[2]).max())
+
+
+def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max=False, tol_xtbl=1e-3, pair_row=None, twin=None):
     """Returns a log dict; `cols` is modified in place to the current basis.  Replacements whose pivot
     |xtbl| = |(B^-1 a)_j| is below tol_xtbl are not applied (they would make the basis ill-conditioned and the
-    residual checks meaningless).  pair_row[j] = row paired with column j in the INITIAL factorization."""
+    residual checks meaningless).  pair_row[j] = row paired with column j in the INITIAL factorization.
+    twin: a second object (the CPU restatement of the same intended algorithm) driven in lockstep; every status,
+    pattern and value must be identical to h's."""
     log = dict(done=0, skipped=0, singular=0, max_residual=0.0, max_vs_fresh=0.0, max_pivot_error=0.0, hit_maximum_updates=False,
                max_sparse_diff=0.0)
     B = matrix_of(cols, m)
     for step in range(nupd):
         j = int(rng.integers(0, m))
         ai, ax = new_column(rng, cols, m, j, pair_row)
-        st, il, row = h.solve_for_update([j], None, "T")
+        st, il, row = _sfu(h, [j], None, "T")
+        if twin is not None:
+            _same((st, il, row), _sfu(twin, [j], None, "T"), ("solve_for_update T", step))
         if st == K.ERROR_MAXIMUM_UPDATES:
             log["hit_maximum_updates"] = True
             if stop_on_max:
@@ -97,7 +124,9 @@ def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max
         ej[j] = 1.0
         log["max_residual"] = max(log["max_residual"], backward_error(B.T, row, ej))
         assert np.array_equal(np.sort(il), np.flatnonzero(row)), "pattern of the transposed solution"
-        st, il2, lhs = h.solve_for_update(ai, ax, "N")
+        st, il2, lhs = _sfu(h, ai, ax, "N")
+        if twin is not None:
+            _same((st, il2, lhs), _sfu(twin, ai, ax, "N"), ("solve_for_update N", step))
         assert st == K.OK, st
         a = np.zeros(m)
         a[ai] = ax
@@ -108,6 +137,11 @@ def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max
             log["skipped"] += 1
             continue
         st = h.update(xtbl)
+        if twin is not None:
+            assert twin.update(xtbl) == st, ("update status", step)
+            for key in (K.STAT_NFORREST, K.STAT_NUPDATE, K.STAT_R_NZ, K.STAT_PIVOT_ERROR, K.STAT_NSYMPERM_TOTAL, K.STAT_DEV_NUNSYMPERM_TOTAL,
+                        K.STAT_MIN_PIVOT, K.STAT_MAX_PIVOT, K.STAT_MAX_ETA, K.STAT_U_NZ):
+                assert h.stat(key) == twin.stat(key), ("stat", key, step, h.stat(key), twin.stat(key))
         if st == K.ERROR_SINGULAR_UPDATE:
             log["singular"] += 1
             continue
@@ -120,6 +154,8 @@ def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max
             b = rng.standard_normal(m)
             x = h.solve_dense(b, "N")
             xt = h.solve_dense(b, "T")
+            if twin is not None:
+                assert np.array_equal(x, twin.solve_dense(b, "N")) and np.array_equal(xt, twin.solve_dense(b, "T")), ("solve_dense", step)
             log["max_residual"] = max(log["max_residual"], backward_error(B, x, b), backward_error(B.T, xt, b))
             # sparse solves on the updated factorization
             nz = int(rng.integers(1, max(2, m // 10)))
@@ -128,9 +164,11 @@ def run_updates(h, cols, m, nupd, rng, refactor=None, check_every=1, stop_on_max
             bs = np.zeros(m)
             bs[ir] = xr
             for trans, A in (("N", B), ("T", B.T)):
-                out = h.solve_sparse(ir, xr, trans)
-                sol = out[2] if isinstance(out, tuple) else h.lhs
-                assert (out[0] if isinstance(out, tuple) else out) == K.OK
+                out = _ss(h, ir, xr, trans)
+                if twin is not None:
+                    _same(out, _ss(twin, ir, xr, trans), ("solve_sparse", trans, step))
+                sol = out[2]
+                assert out[0] == K.OK
                 log["max_residual"] = max(log["max_residual"], backward_error(A, sol, bs))
             if refactor is not None:
                 f = refactor(cols)
