@@ -315,6 +315,11 @@ class BLU:
         lib().blu_hip_set_skip_stats.argtypes = [C.c_void_p, C.c_int]
         lib().blu_hip_set_skip_stats(self._h, int(bool(on)))
 
+    def dbg_set_upd_extra(self, n):
+        """Arena slack of the update path (entries); small values force the host-side growth loop."""
+        lib().blu_hip_dbg_set_upd_extra.argtypes = [C.c_void_p, C.c_int64]
+        lib().blu_hip_dbg_set_upd_extra(self._h, int(n))
+
     def dbg_set_no_fast(self, on=True):
         """Run the general pivot paths only (k_pivot_fast.hip off): A/B of the two implementations."""
         lib().blu_hip_dbg_set_no_fast.argtypes = [C.c_void_p, C.c_int]

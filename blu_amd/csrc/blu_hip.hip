@@ -66,6 +66,7 @@ struct blu_hip {
     UpdState ust;           // last downloaded state
     int64_t upd_alloc_m;    // m the fixed-size arrays of uw were allocated for (-1: none)
     int64_t upd_for_nfact;  // nfactorize uw was built for (-1: none)
+    int64_t upd_extra;      // debug: arena slack of the update path (-1: default)
     int64_t sp_l_flops, sp_u_flops; // lu.l_flops / lu.u_flops
     int sp_branch;                  // 1 sparse, 2 sequential: branch of the last solve_sparse (diagnostic)
     // timing
@@ -210,6 +211,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     memset(&h->ust, 0, sizeof(UpdState));
     h->upd_alloc_m = -1;
     h->upd_for_nfact = -1;
+    h->upd_extra = -1;
     h->stop_at = -1;
     h->block_threads = 1024;
     h->no_fast = 0;

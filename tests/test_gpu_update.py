@@ -109,6 +109,7 @@ def test_maximum_updates_and_storage_growth(blu, oracle):
     cp, ri, v = oracle.gen_lp_basis(*spec)
     m = spec[0]
     g = blu.BLU(m, 4)
+    g.dbg_set_upd_extra(8)  # forces UPD_NEED_R / NEED_UC / NEED_W round trips
     o = oracle.OracleBLU(m, 256 * len(ri))
     assert g.factorize(cp[:-1], cp[1:], ri, v) == o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
     cols = U.columns_of(cp, ri, v)
