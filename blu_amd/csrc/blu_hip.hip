@@ -330,9 +330,10 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_NUPDATE: return (double)h->nupdate;
     case BLU_STAT_NFACTORIZE: return (double)h->nfactorize;
     case BLU_STAT_L_NZ: return (double)s.l_nz;
-    case BLU_STAT_U_NZ: return (double)s.u_nz;
-    case BLU_STAT_MIN_PIVOT: return s.min_pivot;
-    case BLU_STAT_MAX_PIVOT: return s.max_pivot;
+    // after an update these three live in the update state (update.rs:242-255, 625-626, 853-854, 943)
+    case BLU_STAT_U_NZ: return h->nupdate > 0 ? (double)h->ust.u_nz : (double)s.u_nz;
+    case BLU_STAT_MIN_PIVOT: return h->nupdate > 0 ? h->ust.min_pivot : s.min_pivot;
+    case BLU_STAT_MAX_PIVOT: return h->nupdate > 0 ? h->ust.max_pivot : s.max_pivot;
     case BLU_STAT_CONDEST_L: return s.condest_l;
     case BLU_STAT_CONDEST_U: return s.condest_u;
     case BLU_STAT_NORM_L: return s.norm_l;
