@@ -218,6 +218,20 @@ __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1u
 // Communication BETWEEN waves goes through __syncthreads().
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+// Broadcast of one lane's value when the source lane is the same for the whole wave (derived from a ballot):
+// v_readlane with the lane number in a scalar register -- a few cycles -- instead of __shfl, which compiles
+// to ds_bpermute (an LDS-crossbar round trip, ~100 cycles of latency on a dependent chain).
+__device__ __forceinline__ int wave_bcast_i(int v, int src)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
+__device__ __forceinline__ double wave_bcast_d(double v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s), hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
+
 // Wave-wide all-reductions through rocPRIM's DPP implementation (row_shr / row_bcast data-parallel
 // primitives: ~6 VALU ops per 32-bit word) instead of __shfl_xor butterflies, which compile to
 // ds_bpermute (an LDS-crossbar round trip per step) -- measured 3-4x cheaper on the pivot loop's

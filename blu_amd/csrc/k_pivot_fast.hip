@@ -431,7 +431,7 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
         while (ne && ncand < K && !bad) {
             const int b = __ffsll((long long)ne) - 1;
             ne &= ne - 1;
-            int j = __shfl(h, b);
+            int j = wave_bcast_i(h, b);
             const int znz = nz + b;
             int guard = 0;
             while (j < m && ncand < K) {
@@ -628,25 +628,49 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
     }
     if (kind == 0) return;
 
-    // ---- pivot column into LDS; kind 1: pivot swapped to the front (pivot.rs:169-170)
-    const int coff = fa->cOff[csel];
-    for (int e = lane; e < nzc; e += 64) {
-        const int slot = (e == where) ? 0 : (e == 0 ? where : e);
-        fa->pcI[slot] = fa->sI[coff + e];
-        fa->pcV[slot] = fa->sV[coff + e];
-        fa->prB[slot] = fa->sB[coff + e];
-        fa->prL[slot] = fa->sL[coff + e];
-        fa->prC[slot] = fa->sC[coff + e];
-    }
-    // ---- pivot row into LDS; kind 1: pivot column swapped to the front (pivot.rs:185)
+    // Order of the steps below: every global load is issued as early as its address is known and the LDS work
+    // that does not depend on it runs while it is in flight (pivot row || pivot column copy; column metadata ||
+    // row hash).
+    // ---- pivot row: loads issued first; kind 1: pivot column swapped to the front later (pivot.rs:185)
     int jq[PRMAX / 64];
-    int wpos = -1;
 #pragma unroll
     for (int c = 0; c < PRMAX / 64; c++) {
         jq[c] = -1;
         if (c * 64 < nzr) { // (rows are mostly shorter than 64: one chunk)
             const int q = c * 64 + lane;
-            jq[c] = q < nzr ? D.ridx[prb + q] : -1;
+            if (q < nzr) jq[c] = D.ridx[prb + q];
+        }
+    }
+    if (kind == 1) {
+        for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
+    }
+    for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
+    // ---- pivot column into LDS; kind 1: pivot swapped to the front (pivot.rs:169-170)
+    const int coff = fa->cOff[csel];
+    int hr_idx[(PCMAX + 63) / 64], hr_slot[(PCMAX + 63) / 64], hr_len[(PCMAX + 63) / 64];
+#pragma unroll
+    for (int c = 0; c < (PCMAX + 63) / 64; c++) {
+        const int e = c * 64 + lane;
+        hr_slot[c] = 0;
+        hr_idx[c] = 0;
+        hr_len[c] = 0;
+        if (e < nzc) {
+            const int slot = (e == where) ? 0 : (e == 0 ? where : e);
+            const int idx = fa->sI[coff + e], rlv = fa->sL[coff + e];
+            fa->pcI[slot] = idx;
+            fa->pcV[slot] = fa->sV[coff + e];
+            fa->prB[slot] = fa->sB[coff + e];
+            fa->prL[slot] = rlv;
+            fa->prC[slot] = fa->sC[coff + e];
+            hr_slot[c] = slot;
+            hr_idx[c] = idx;
+            hr_len[c] = rlv;
+        }
+    }
+    int wpos = -1;
+#pragma unroll
+    for (int c = 0; c < PRMAX / 64; c++) {
+        if (c * 64 < nzr) {
             const unsigned long long hb = __ballot(jq[c] == pc);
             if (hb) wpos = c * 64 + __ffsll((long long)hb) - 1;
         }
@@ -657,18 +681,37 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
         return;
     }
     PROF_STAMP(12); // pivot column copied, pivot row loaded
-    if (kind == 1) {
-        for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
+    // ---- (begin,len,cap) of the pivot row's columns: loads issued, the row hash is built meanwhile
+    int tbq[PRMAX / 64], tlq[PRMAX / 64], tcq[PRMAX / 64];
+#pragma unroll
+    for (int c = 0; c < PRMAX / 64; c++) {
+        const int q = c * 64 + lane;
+        tbq[c] = tlq[c] = tcq[c] = 0;
+        if (c * 64 < nzr && q < nzr) {
+            const int j = jq[c];
+            tbq[c] = D.cbeg[j];
+            tlq[c] = D.clen[j];
+            tcq[c] = D.ccap[j];
+        }
     }
-    for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
     long long gc = 0, gr = 0;
+    if (kind == 1) {
+#pragma unroll
+        for (int c = 0; c < (PCMAX + 63) / 64; c++) {
+            if (hr_slot[c] >= 1) {
+                hrow_insert(fa, hr_idx[c], hr_slot[c]);
+                const int n = hr_len[c] + nzr - 1;
+                gr += n + stretch_of(D.stretch, n) + D.pad;
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < PRMAX / 64; c++) {
         const int q = c * 64 + lane;
         if (c * 64 < nzr && q < nzr) {
             const int j = jq[c];
             const int slot = kind == 1 ? ((q == wpos) ? 0 : (q == 0 ? wpos : q)) : q;
-            const int tb = D.cbeg[j], tl = D.clen[j], tc = D.ccap[j];
+            const int tb = tbq[c], tl = tlq[c], tc = tcq[c];
             fa->tJ[slot] = j;
             fa->tB[slot] = tb;
             fa->tL[slot] = tl;
@@ -680,13 +723,8 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
             }
         }
     }
-    PROF_STAMP(13); // line metadata of the pivot row's columns loaded, column hash built
+    PROF_STAMP(13); // line metadata of the pivot row's columns loaded, both hashes built
     if (kind == 1) {
-        for (int p = 1 + lane; p < nzc; p += 64) {
-            hrow_insert(fa, fa->pcI[p], p);
-            const int n = fa->prL[p] + nzr - 1;
-            gr += n + stretch_of(D.stretch, n) + D.pad;
-        }
         // one reduction for both room estimates (each below 2^31: <= 256 lines of < 2^22 entries)
         const long long both = wave_sum_ll((gc << 32) | (gr & 0xffffffffLL));
         gc = both >> 32;
@@ -804,14 +842,14 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *
         const unsigned long long pb = __ballot(ispr);
         if (pb) {
             const int src = __ffsll((long long)pb) - 1;
-            where = __shfl(t, src);
-            xrj = __shfl(val, src);
+            where = wave_bcast_i(t, src);
+            xrj = wave_bcast_d(val, src);
         }
         const unsigned long long fb = __ballot(keep && t == 0);
         if (fb) {
             const int src = __ffsll((long long)fb) - 1;
-            first_idx = __shfl(idx, src);
-            first_val = __shfl(val, src);
+            first_idx = wave_bcast_i(idx, src);
+            first_val = wave_bcast_d(val, src);
         }
         if (keep && !ispr) {
             const double x = fabs(val);
@@ -834,7 +872,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *
         newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
         int nb = 0;
         if (lane == 0) nb = atomicAdd(&sm->cused, newcap);
-        dst = __shfl(nb, 0);
+        dst = __builtin_amdgcn_readfirstlane(nb);
     }
     if (cl <= 64) {
         if (keep0 && t0r != where && t0r > 0) {
@@ -941,7 +979,7 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, int p, int j_fi
         newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
         int nb = 0;
         if (lane == 0) nb = atomicAdd(&sm->rused, newcap);
-        dst = __shfl(nb, 0);
+        dst = __builtin_amdgcn_readfirstlane(nb);
     }
     if (rl <= 64) {
         if (keep0) D.ridx[dst + t0r] = j0;
@@ -1299,7 +1337,7 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
             if (hb) {
                 const int src = __ffsll((long long)hb) - 1;
                 where = c + src;
-                xrj = __shfl(val, src);
+                xrj = wave_bcast_d(val, src);
             }
             if (v && idx != pr) {
                 const double x = fabs(val);
