@@ -1194,8 +1194,9 @@ __device__ COLD void setup_pivot_general(const DevGP &D, Sm *sm)
 
 // BATCH: the 4-wave workgroups of the batch kernel cannot spare a wave for the split list update and the
 // early search; leaving that code out also relieves its tighter register budget.
+// mc: the metadata cache of the single-matrix kernel (k_pivot_fast_types.h), nullptr in the batch kernel
 template <bool BATCH>
-__device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
+__device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, Mc *mc)
 {
     const DevGP D(&Ds[blockIdx.x]);
     Scalars *S = D.s;
@@ -1234,6 +1235,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
         g_pivot_err = 0;
         g_pivot_err_line = 0;
     }
+    if (mc) mc_reset(D, mc, tid, (int)blockDim.x);
     __syncthreads();
 
     // Three workgroup barriers per pivot: wave 0 alone runs [record previous pivot -> loop head -> search
@@ -1252,6 +1254,12 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
                 sm->head_exit = sm->exit_code;
             }
             wave_mem_sync();
+            // something wrote list links straight to global memory since the last search (a general pivot path,
+            // remove_col, the empty-column step): reload the LDS copies of the list heads
+            if (mc && mc->dirty) {
+                mc_reset(D, mc, lane, 64);
+                wave_mem_sync();
+            }
             PROF_STAMP(0);
             // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
             // The searching wave also lays out the pivot (positions, L/U room check, and for the two
@@ -1259,7 +1267,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
             if (!sm->head_exit) {
                 bool handled = false;
                 if (sm->need_search) {
-                    if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast<BATCH>(D, sm, ew_mcb, ew_fb);
+                    if (D.search_rows == 0 && !D.no_fast) handled = markowitz_fast<BATCH>(D, sm, mc, ew_mcb, ew_fb);
                     if (!handled) {
                         if (D.search_rows == 0) markowitz_wave(D, sm);
                         else if (lane == 0) markowitz_serial(D, sm);
@@ -1287,7 +1295,8 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
             __syncthreads(); // every thread has read sm->pr / sm->pc before thread 0 rewrites them
             if (tid == 0) {
                 list_remove1(D.cflink, D.cblink, pc);
-                        sm->pc = -1;
+                if (mc) mc->dirty = 1;
+                sm->pc = -1;
                 sm->rankdef++;
                 sm->kinds[5]++;
             }
@@ -1301,12 +1310,15 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
         const int nz_col = dB.x, nz_row = dB.y;
         const int kind = dC.x;
         bool ok = true;
-        if (kind == 1) fast_small<BATCH>(D, sm, pr, pc, nz_col, nz_row, ew_mcb, ew_fb);
-        else if (kind == 2) fast_scol<BATCH>(D, sm, pr, pc, nz_row, dC.y, ew_mcb, ew_fb);
-        else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
-        else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
-        else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
-        else ok = pivot_general(D, sm, nz_col - 1 <= 64);
+        if (kind == 1) fast_small<BATCH>(D, sm, mc, pr, pc, nz_col, nz_row, ew_mcb, ew_fb);
+        else if (kind == 2) fast_scol<BATCH>(D, sm, mc, pr, pc, nz_row, dC.y, ew_mcb, ew_fb);
+        else {
+            if (mc && tid == 0) mc->dirty = 1; // the general paths work on global memory only
+            if (nz_row == 1) ok = pivot_singleton_row(D, sm);
+            else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
+            else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
+            else ok = pivot_general(D, sm, nz_col - 1 <= 64);
+        }
         if (!ok) break; // exit_code set, pivot stays pending
         PROF_STAMP(2);
 #ifdef BLU_PROFILE
@@ -1375,7 +1387,10 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
             if (sm->flag_small && nz_row > 1) {
                 for (int pos = D.ubeg[rank]; pos < D.ubeg[rank + 1]; pos++) {
                     const int j = D.uidx[pos];
-                    if (D.colmax[j] == 0.0 || D.colmax[j] < D.abstol) remove_col_serial(D, sm, j);
+                    if (D.colmax[j] == 0.0 || D.colmax[j] < D.abstol) {
+                        remove_col_serial(D, sm, j);
+                        if (mc) mc->dirty = 1;
+                    }
                 }
             }
             sm->flops += (long long)(nz_col - 1) * (long long)(nz_row - 1);
@@ -1419,7 +1434,8 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm)
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
     __shared__ Sm smem;
-    pivot_loop_body<false>(Ds, stop_at, &smem);
+    __shared__ Mc mcache;
+    pivot_loop_body<false>(Ds, stop_at, &smem, &mcache);
 }
 // Many matrices (batch): workgroups of <= 256 threads = 4 waves, so only 4 of the 16 work columns at the
 // end of Sm are allocated, and a register budget for BLU_BATCH_WAVES waves per SIMD: that many
@@ -1431,5 +1447,5 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BLU_BA
 k_pivot_loop_batch(DevLU *Ds, int stop_at)
 {
     __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - 12 * 64 * sizeof(double)];
-    pivot_loop_body<true>(Ds, stop_at, reinterpret_cast<Sm *>(raw));
+    pivot_loop_body<true>(Ds, stop_at, reinterpret_cast<Sm *>(raw), nullptr);
 }

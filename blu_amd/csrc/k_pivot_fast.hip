@@ -75,6 +75,19 @@ __device__ __forceinline__ bool hcol_has(const Fast *f, int k)
     probe_overrun(__LINE__);
     return false;
 }
+// slot of column k in the pivot row laid out by the last mk_pick, or -1
+__device__ __forceinline__ int hcol_slot(const Fast *f, int k)
+{
+    unsigned s = hslot(k, HCOL_BITS);
+    for (int n = 0; n < HCOL; n++) {
+        const unsigned long long x = f->hCol[s];
+        if ((int)(x >> 32) == k) return (int)(x & 0xffffffffull);
+        if (x == ~0ull) return -1;
+        s = (s + 1) & (HCOL - 1);
+    }
+    probe_overrun(__LINE__);
+    return -1;
+}
 // Three look-ups at once in a table of (key << 32 | value) words: the probes of the three keys are
 // issued together, so the whole costs about one LDS round trip.  r = value, or -1 if the key is absent
 // (or its look-up not wanted).
@@ -110,6 +123,61 @@ __device__ __forceinline__ void hash_find3(const unsigned long long *H, int k1, 
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Links of the column count lists with the heads / tails of the short lists in LDS (Mc, k_pivot_fast_types.h).
+// mc == nullptr (batch kernel): plain global accesses; every branch on mc folds away after inlining.
+// ------------------------------------------------------------------------------------------------
+struct LinksC {
+    const DevGP &D;
+    Mc *mc;
+    __device__ __forceinline__ int fl(int e) const
+    {
+        const int k = e - D.m;
+        if (mc && k >= 0 && k < MC_HEADS) return mc->hf[k];
+        return D.cflink[e];
+    }
+    __device__ __forceinline__ int bl(int e) const
+    {
+        const int k = e - D.m;
+        if (mc && k >= 0 && k < MC_HEADS) return mc->hb[k];
+        return D.cblink[e];
+    }
+    __device__ __forceinline__ void set_fl(int e, int v) const
+    {
+        D.cflink[e] = v;
+        const int k = e - D.m;
+        if (mc && k >= 0 && k < MC_HEADS) mc->hf[k] = v;
+    }
+    __device__ __forceinline__ void set_bl(int e, int v) const
+    {
+        D.cblink[e] = v;
+        const int k = e - D.m;
+        if (mc && k >= 0 && k < MC_HEADS) mc->hb[k] = v;
+    }
+};
+// the same interface over two plain arrays (row count lists)
+struct LinksG {
+    gint_p f, b;
+    __device__ __forceinline__ int fl(int e) const { return f[e]; }
+    __device__ __forceinline__ int bl(int e) const { return b[e]; }
+    __device__ __forceinline__ void set_fl(int e, int v) const { f[e] = v; }
+    __device__ __forceinline__ void set_bl(int e, int v) const { b[e] = v; }
+};
+// (re)loads the LDS copies of the list heads: at the start of a launch (every thread) and, by wave 0 alone,
+// after anything that wrote links straight to global memory (general pivot paths, remove_col)
+__device__ __forceinline__ void mc_reset(const DevGP &D, Mc *mc, int first, int step)
+{
+    for (int k = first; k < MC_HEADS; k += step) {
+        const bool in = k <= D.m + 1;
+        mc->hf[k] = in ? D.cflink[D.m + k] : 0;
+        mc->hb[k] = in ? D.cblink[D.m + k] : 0;
+    }
+    if (first == 0) {
+        mc->dirty = 0;
+        mc->prevValid = 0;
+    }
+}
+
 // The element sets of the batched list moves: membership, and the lanes that handle three elements in
 // wave_list_move_batch_set (lane q holds elems[q]; lane n the element that is only removed).
 struct InHCol {
@@ -152,8 +220,8 @@ struct InHRow {
 //                         tail-append.  Returns the smallest key > 0.
 // skip = index in elems of an element that is not moved (the pivot column inside a singleton-column
 // pivot row, which is `gone`), or -1.
-template <class InSet>
-__device__ __forceinline__ void wave_list_unlink_set(gint_p flink, gint_p blink, const int *elems, int n, int skip, InSet inS, int gone)
+template <class Links, class InSet>
+__device__ __forceinline__ void wave_list_unlink_set(const Links &L, const int *elems, int n, int skip, InSet inS, int gone)
 {
     const int lane = lane_id();
     const bool mov = lane < n && lane != skip;
@@ -161,8 +229,8 @@ __device__ __forceinline__ void wave_list_unlink_set(gint_p flink, gint_p blink,
     const int e = mov ? elems[lane] : (unl ? gone : 0);
     int p = 0, nx = 0;
     if (unl) {
-        p = blink[e];
-        nx = flink[e];
+        p = L.bl(e);
+        nx = L.fl(e);
     }
     int sl, pl, dummy;
     inS.lanes_of(nx, p, 0, unl, unl, false, n, sl, pl, dummy);
@@ -178,23 +246,25 @@ __device__ __forceinline__ void wave_list_unlink_set(gint_p flink, gint_p blink,
         }
     }
     if (first) {
-        flink[p] = fs;
-        blink[fs] = p;
+        L.set_fl(p, fs);
+        L.set_bl(fs, p);
     }
     if (lane == n && gone >= 0) {
-        flink[gone] = gone;
-        blink[gone] = gone;
+        L.set_fl(gone, gone);
+        L.set_bl(gone, gone);
     }
 }
-__device__ __forceinline__ int wave_list_append_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n, int big,
-                                                    unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
+// pfl (optional): pfl[q] receives the new forward link of element q (for the next search: Mc::pFl)
+template <class Links>
+__device__ __forceinline__ int wave_list_append_set(const Links &L, int nelem, const int *elems, const int *keys, int n, int big,
+                                                    unsigned long long *kg /* KGMAX words of LDS, all zero between calls */, int *pfl = nullptr)
 {
     const int lane = lane_id();
     const int key = lane < n ? keys[lane] : -1;
     const bool act = key >= 0;
     const int e = act ? elems[lane] : 0;
     int t = 0;
-    if (act) t = blink[nelem + key];
+    if (act) t = L.bl(nelem + key);
     // while the load is in flight: neighbours inside the new list = nearest lanes below / above with the same key
     unsigned long long mygrp = 0ull;
     if (!__ballot(act && key >= KGMAX)) {
@@ -221,10 +291,11 @@ __device__ __forceinline__ int wave_list_append_set(gint_p flink, gint_p blink, 
     const int eprev = prevl >= 0 ? elems[prevl] : 0, enext = nextl >= 0 ? elems[nextl] : 0;
     const int minall = wave_min_i(act && key > 0 ? key : big);
     if (act) {
-        blink[e] = prevl >= 0 ? eprev : t;
-        flink[e] = nextl >= 0 ? enext : nelem + key;
-        if (prevl < 0) flink[t] = e;
-        if (nextl < 0) blink[nelem + key] = e;
+        L.set_bl(e, prevl >= 0 ? eprev : t);
+        L.set_fl(e, nextl >= 0 ? enext : nelem + key);
+        if (pfl) pfl[lane] = nextl >= 0 ? enext : nelem + key;
+        if (prevl < 0) L.set_fl(t, e);
+        if (nextl < 0) L.set_bl(nelem + key, e);
     }
     return minall;
 }
@@ -233,8 +304,8 @@ __device__ __forceinline__ int wave_list_append_set(gint_p flink, gint_p blink, 
 // as a membership predicate instead of a mark array.  elems/keys may live in LDS.
 // `gone` (>= 0): one more element of the set that is only unlinked, not re-appended (the pivot
 // column / pivot row, list.rs:81-86 at the end of every pivot path).
-template <class InSet>
-__device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p blink, int nelem, const int *elems, const int *keys, int n,
+template <class Links, class InSet>
+__device__ __forceinline__ int wave_list_move_batch_set(const Links &L, int nelem, const int *elems, const int *keys, int n,
                                         InSet inS, int big, int gone,
                                         unsigned long long *kg /* KGMAX words of LDS, all zero between calls */)
 {
@@ -253,11 +324,11 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
         const int e = act ? elems[lane] : (unl ? gone : 0);
         int p = 0, nx = 0, t = 0;
         if (unl) {
-            p = blink[e];
-            nx = flink[e];
+            p = L.bl(e);
+            nx = L.fl(e);
         }
         if (act) {
-            t = blink[nelem + key];
+            t = L.bl(nelem + key);
             if (key > 0) minkey = key;
         }
         // While the three loads are in flight: neighbours inside the new list = nearest lanes below /
@@ -317,42 +388,48 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
             }
         }
         if (first) { // link the run's unmoved predecessor to its unmoved successor
-            flink[p] = fs;
-            blink[fs] = p;
+            L.set_fl(p, fs);
+            L.set_bl(fs, p);
         }
         PROF_STAMP_L0(30);
         // the old tail is being moved itself: the real tail is its nearest unmoved predecessor
         const int tfix = __shfl(fp, tl >= 0 ? tl : lane);
         if (act && tl >= 0) t = tfix;
         if (lane == n && gone >= 0) { // list.rs:84-85: a removed element links to itself
-            flink[gone] = gone;
-            blink[gone] = gone;
+            L.set_fl(gone, gone);
+            L.set_bl(gone, gone);
         }
         PROF_STAMP_L0(31);
         if (act) {
-            blink[e] = prevl >= 0 ? eprev : t;
-            flink[e] = nextl >= 0 ? enext : nelem + key;
-            if (prevl < 0) flink[t] = e;
-            if (nextl < 0) blink[nelem + key] = e;
+            L.set_bl(e, prevl >= 0 ? eprev : t);
+            L.set_fl(e, nextl >= 0 ? enext : nelem + key);
+            if (prevl < 0) L.set_fl(t, e);
+            if (nextl < 0) L.set_bl(nelem + key, e);
         }
         PROF_STAMP_L0(28);
         return minall; // no drain here: the workgroup barrier that follows waits for the stores
     }
     if (gone >= 0) { // long batches: unlink `gone` first, as the general path does
-        if (lane == 0) list_remove1(flink, blink, gone);
+        if (lane == 0) { // list_remove1 through the accessor
+            const int f = L.fl(gone), b = L.bl(gone);
+            L.set_fl(b, f);
+            L.set_bl(f, b);
+            L.set_fl(gone, gone);
+            L.set_bl(gone, gone);
+        }
         wave_mem_sync();
     }
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int q = c0 + lane;
         if (q < n && keys[q] >= 0) {
             const int e = elems[q];
-            const int p = blink[e];
-            int nx = flink[e];
+            const int p = L.bl(e);
+            int nx = L.fl(e);
             const bool prev_marked = p < nelem && inS(p);
             if (!prev_marked) {
-                for (int guard = 0; nx < nelem && inS(nx) && guard <= n; guard++) nx = flink[nx];
-                flink[p] = nx;
-                blink[nx] = p;
+                for (int guard = 0; nx < nelem && inS(nx) && guard <= n; guard++) nx = L.fl(nx);
+                L.set_fl(p, nx);
+                L.set_bl(nx, p);
             }
         }
     }
@@ -368,17 +445,17 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
             const int leader = __ffsll((long long)active) - 1;
             const int k = __shfl(key, leader);
             const unsigned long long grp = __ballot(act && key == k);
-            const int tail = blink[nelem + k];
+            const int tail = L.bl(nelem + k);
             const unsigned long long below = grp & lanes_below(lane);
             const unsigned long long above = grp & ~((2ull << lane) - 1ull);
             const int prevl = below ? 63 - __clzll((long long)below) : 0;
             const int nextl = above ? __ffsll((long long)above) - 1 : 0;
             const int pe = __shfl(e, prevl), ne = __shfl(e, nextl);
             if (act && key == k) {
-                blink[e] = below ? pe : tail;
-                flink[e] = above ? ne : nelem + k;
-                if (!below) flink[tail] = e;
-                if (!above) blink[nelem + k] = e;
+                L.set_bl(e, below ? pe : tail);
+                L.set_fl(e, above ? ne : nelem + k);
+                if (!below) L.set_fl(tail, e);
+                if (!above) L.set_bl(nelem + k, e);
                 act = false;
             }
             active &= ~grp;
@@ -401,7 +478,7 @@ __device__ __forceinline__ int wave_list_move_batch_set(gint_p flink, gint_p bli
 //             LDS, hash sets, room checks, fa->kind
 // mk_walk returns: 0 candidates found, 1 empty column chosen (pr = -1), 2 error, 3 shape not handled
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
+__device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm, Mc *mc)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -409,7 +486,8 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
     if (K < 1 || K > KCMAX || m >= (1 << 27)) return 3; // (cost*256 + position must fit 64 bits)
-    const int h0 = D.cflink[m];
+    const LinksC LC{D, mc};
+    const int h0 = LC.fl(m);
     if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
         if (lane == 0) {
             sm->pc = h0;
@@ -422,7 +500,7 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
     bool bad = false;
     while (ncand < K && nz <= m && !bad) {
         const int k = nz + lane;
-        const int h = k <= m ? D.cflink[m + k] : m + k;
+        const int h = k <= m ? LC.fl(m + k) : m + k;
         unsigned long long ne = __ballot(k <= m && h != m + k);
         if (ncand == 0) {
             PROF_WAIT();
@@ -435,9 +513,25 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
             const int znz = nz + b;
             int guard = 0;
             while (j < m && ncand < K) {
-                const int fl = D.cflink[j];
-                const int cb = D.cbeg[j], cl = D.clen[j];
-                const double cmx = D.colmax[j];
+                // a column moved by the previous pivot: new length, begin, maximum and link are still in LDS
+                int fl, cb, cl;
+                double cmx;
+                int ps = -1;
+                if (mc && mc->prevValid) {
+                    ps = hcol_slot(fa, j);
+                    if (ps < mc->prevBase || ps >= MC_PREV || fa->tNew[ps] < 0) ps = -1;
+                }
+                if (ps >= 0) {
+                    fl = mc->pFl[ps];
+                    cb = fa->tB[ps];
+                    cl = fa->tNew[ps];
+                    cmx = fa->tMx[ps];
+                } else {
+                    fl = D.cflink[j];
+                    cb = D.cbeg[j];
+                    cl = D.clen[j];
+                    cmx = D.colmax[j];
+                }
                 if (ncand == 0) {
                     PROF_WAIT();
                     PROF_STAMP(20);
@@ -478,7 +572,7 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm)
     return 0;
 }
 
-__device__ __forceinline__ void mk_stage(const DevGP &D, Sm *sm, long long &mcb, int &fb)
+__device__ __forceinline__ void mk_stage(const DevGP &D, Sm *sm, Mc *mc, long long &mcb, int &fb)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -532,20 +626,39 @@ __device__ __forceinline__ void mk_stage(const DevGP &D, Sm *sm, long long &mcb,
 // staged: 4 dependent loads (list heads, column, entry, row) instead of 6, and no reduction.
 // Returns false (nothing modified) if the count-1 list is empty or anything is unusual; the caller
 // then takes the ordinary route, which also raises the errors.
-__device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, int &nsearched)
+__device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, Mc *mc, int &nsearched)
 {
     const int lane = lane_id();
     const int m = D.m;
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
     if (K < 1 || K > KCMAX || m >= (1 << 27)) return false;
-    const int h0 = D.cflink[m], j = D.cflink[m + 1];
+    const LinksC LC{D, mc};
+    const int h0 = LC.fl(m), j = LC.fl(m + 1);
     if (h0 != m || j >= m) return false;
-    const int cb = D.cbeg[j], cl = D.clen[j];
-    const double cmx = D.colmax[j];
+    int cb, cl, idx = -1;
+    double cmx, val = 0.0;
+    int ps = -1;
+    if (mc && mc->prevValid) {
+        ps = hcol_slot(fa, j);
+        if (ps < mc->prevBase || ps >= MC_PREV || fa->tNew[ps] < 0) ps = -1;
+    }
+    if (ps >= 0) { // moved by the previous pivot: everything about it is still in LDS
+        cb = fa->tB[ps];
+        cl = fa->tNew[ps];
+        cmx = fa->tMx[ps];
+        idx = mc->e1i[ps];
+        val = mc->e1v[ps];
+    } else {
+        cb = D.cbeg[j];
+        cl = D.clen[j];
+        cmx = D.colmax[j];
+    }
     if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false;
-    const int idx = D.cidx[cb];
-    const double val = D.cval[cb];
+    if (idx < 0) {
+        idx = D.cidx[cb];
+        val = D.cval[cb];
+    }
     const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
     const double tol = fmax(D.abstol, D.reltol * cmx);
     const double x = fabs(val);
@@ -572,7 +685,7 @@ __device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, int &nsearche
 }
 
 // single: one candidate entry (a column singleton): nothing to reduce
-__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, int fb, int nsearched, bool single)
+__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long long mcb, int fb, int nsearched, bool single)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -742,7 +855,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, long long mcb, i
 // the complete search on the current list state.  Returns false if the shape is outside what this path
 // handles (nothing has been modified then; the caller runs the general search).
 template <bool BATCH>
-__device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long ew_mcb, int ew_fb)
+__device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, long long ew_mcb, int ew_fb)
 {
     Fast *fa = &sm->fa;
     if (lane_id() == 0) fa->kind = 0;
@@ -763,10 +876,10 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long
             int nsr2 = 0, fb2 = 0;
             long long mcb2 = 0;
             bool okc = true;
-            if (!mk_express(D, sm, nsr2)) {
-                const int r2 = mk_walk(D, sm);
+            if (!mk_express(D, sm, mc, nsr2)) {
+                const int r2 = mk_walk(D, sm, mc);
                 if (r2 == 0) {
-                    mk_stage(D, sm, mcb2, fb2);
+                    mk_stage(D, sm, mc, mcb2, fb2);
                     nsr2 = fa->ncand;
                 } else {
                     okc = false;
@@ -788,24 +901,24 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long
 #endif
         PROF_STAMP(9);
         PROF_STAMP(10);
-        mk_pick(D, sm, mcb, fb, nsr, true);
+        mk_pick(D, sm, mc, mcb, fb, nsr, true);
         return true;
     }
-    if (mk_express(D, sm, nsr)) {
+    if (mk_express(D, sm, mc, nsr)) {
         PROF_STAMP(9);
         PROF_STAMP(10);
-        mk_pick(D, sm, 0, 0, nsr, true);
+        mk_pick(D, sm, mc, 0, 0, nsr, true);
         return true;
     }
-    const int r = mk_walk(D, sm);
+    const int r = mk_walk(D, sm, mc);
     PROF_STAMP(9); // candidates walked (list heads + up to K link/meta loads)
     if (r == 3) return false;
     if (r != 0) return true; // empty column chosen, or error raised
     long long mcb;
     int fb;
-    mk_stage(D, sm, mcb, fb);
+    mk_stage(D, sm, mc, mcb, fb);
     PROF_STAMP(10); // candidate entries + their row metadata loaded and costed
-    mk_pick(D, sm, mcb, fb, fa->ncand, false);
+    mk_pick(D, sm, mc, mcb, fb, fa->ncand, false);
     return true;
 }
 
@@ -814,7 +927,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, long long
 // ------------------------------------------------------------------------------------------------
 // idx_first/val_first: this lane's entry of the first 64-entry chunk, loaded by the caller ahead of
 // time (the caller issues the loads of all its tasks before processing any of them)
-__device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *work, int idx_first, double val_first, int pr, int cnz1,
+__device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, Mc *mc, int q, double *work, int idx_first, double val_first, int pr, int cnz1,
                                          double pivot)
 {
     const int lane = lane_id();
@@ -931,9 +1044,10 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *
         D.ccap[j] = newcap;
         D.colmax[j] = cmx;
         fa->tNew[q] = newlen;
-        if (BLU_EARLY && q < 64) { // new begin and maximum: the early search of the next pivot reads them
+        if (q < 64) { // new begin and maximum: the (early) search of the next pivot reads them
             fa->tB[q] = dst;
             fa->tMx[q] = cmx;
+            if (mc) mc->e1i[q] = -1;
         }
         fa->tX[q] = xrj;
         fa->tM[q] = mask;
@@ -946,7 +1060,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, int q, double *
 
 // kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
 // cancelled by fast_col are removed afterwards by fast_fixrow.
-__device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, int p, int j_first, int pc, int rnz1)
+__device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, int j_first, int pc, int rnz1)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -1008,7 +1122,7 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, int p, int j_fi
 }
 
 // rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
-__device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, int p)
+__device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, Mc *mc, int p)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
@@ -1105,7 +1219,7 @@ __device__ __forceinline__ void fast_write_l(const DevGP &D, Sm *sm)
 // result with the ordinary search.  Not attempted: a column became empty or numerically null, a
 // cancellation fix-up is pending, row search is on, the long form of the list update was taken.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *elems, const int *keys, const int *begs, const double *maxs,
+__device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, const int *elems, const int *keys, const int *begs, const double *maxs,
                                              int n, long long &ew_mcb, int &ew_fb)
 {
     const int lane = lane_id();
@@ -1124,7 +1238,7 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *
     // ---- column singletons first (mk_express's case, half of all pivots): the head of list 1 if it is an
     // unmoved column, else the first moved column whose new count is 1
     {
-        const int h1 = D.cflink[m + 1];
+        const int h1 = LinksC{D, mc}.fl(m + 1);
         const unsigned long long one = __ballot(kq == 1);
         int j = -1, cb = 0;
         double cmx = 0.0;
@@ -1180,7 +1294,7 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, const int *
 // kind 1, whole workgroup
 // ------------------------------------------------------------------------------------------------
 template <bool BATCH>
-__device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int pc, int nzc, int nzr, long long &ew_mcb, int &ew_fb)
+__device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int pr, int pc, int nzc, int nzr, long long &ew_mcb, int &ew_fb)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1202,7 +1316,8 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     // half follows in the finalize step).
     const bool split = !BATCH && nw >= 8 && rnz1 < 64;
     const int nwt = split ? nw - 1 : nw;
-    if (split && w == nw - 1) wave_list_unlink_set(D.cflink, D.cblink, fa->tJ + 1, rnz1, -1, InHCol{fa, 1, 0}, pc);
+    const LinksC LC{D, mc};
+    if (split && w == nw - 1) wave_list_unlink_set(LC, fa->tJ + 1, rnz1, -1, InHCol{fa, 1, 0}, pc);
     for (int base = 0; base < ntask && w < nwt; base += 3 * nwt) {
         int li[3], tt[3];
         double lv[3];
@@ -1246,8 +1361,8 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             const int t = tt[u];
-            if (t < rnz1) fast_col(D, sm, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
-            else if (t < ntask) fast_row(D, sm, t - rnz1 + 1, li[u], pc, rnz1);
+            if (t < rnz1) fast_col(D, sm, mc, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
+            else if (t < ntask) fast_row(D, sm, mc, t - rnz1 + 1, li[u], pc, rnz1);
 #ifdef BLU_PROFILE
             if (w == 1 && base == 0) PROF_STAMP_L0(35 + u);
 #endif
@@ -1263,14 +1378,14 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     __syncthreads();
     PROF_STAMP(3);
     if (fa->anycancel) {
-        for (int p = 1 + w; p <= cnz1; p += nw) fast_fixrow(D, sm, p);
+        for (int p = 1 + w; p <= cnz1; p += nw) fast_fixrow(D, sm, mc, p);
         __syncthreads();
     }
     // finalize step, one job per wave: [0] the search of the NEXT pivot (early_search), [1] L column,
     // [2] count lists, [3] U row and the pivot's own bookkeeping; with fewer than 4 waves (or row search)
     // wave 0 writes the U row instead and the next search waits for the barrier
     const bool early = BLU_EARLY && split && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
+    if (w == 0 && early) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
     if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
         if (lane == 0) {
@@ -1287,17 +1402,20 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
     }
     if (w == 2 % nw) {
         PROF_STAMP_L0(25);
-        const int mn = split ? wave_list_append_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, m + 2, fa->kg[0])
-                             : wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc,
-                                                        fa->kg[0]);
+        const int mn = split ? wave_list_append_set(LC, m, fa->tJ + 1, fa->tNew + 1, rnz1, m + 2, fa->kg[0], mc ? mc->pFl + 1 : nullptr)
+                             : wave_list_move_batch_set(LC, m, fa->tJ + 1, fa->tNew + 1, rnz1, InHCol{fa, 1, 0}, m + 2, pc, fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
+        if (mc && lane == 0) {
+            mc->prevValid = split ? 1 : 0;
+            mc->prevBase = 1;
+        }
         PROF_WAIT();
         PROF_STAMP_L0(29);
     }
     if (D.search_rows && w == 3 % nw) {
         if (lane == 0) list_remove1(D.rflink, D.rblink, pr); // pr is not in the row hash set: unlink it first
         wave_mem_sync();
-        const int mn = wave_list_move_batch_set(D.rflink, D.rblink, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->kg[1]);
+        const int mn = wave_list_move_batch_set(LinksG{D.rflink, D.rblink}, m, fa->pcI + 1, fa->rNew + 1, cnz1, InHRow{fa}, m + 2, -1, fa->kg[1]);
         if (lane == 0 && mn < sm->min_rownz) sm->min_rownz = mn;
     }
     __syncthreads();
@@ -1307,7 +1425,7 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, int pr, int p
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
 // ------------------------------------------------------------------------------------------------
 template <bool BATCH>
-__device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc, int rl, int wq, long long &ew_mcb, int &ew_fb)
+__device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr, int pc, int rl, int wq, long long &ew_mcb, int &ew_fb)
 {
     const int w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
@@ -1319,7 +1437,8 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
     // while the others take the column updates)
     const bool split = !BATCH && nw >= 8 && rl < 64;
     const int nwt = split ? nw - 1 : nw;
-    if (split && w == nw - 1) wave_list_unlink_set(D.cflink, D.cblink, fa->tJ, rl, wq, InHCol{fa, 0, wq}, pc);
+    const LinksC LC{D, mc};
+    if (split && w == nw - 1) wave_list_unlink_set(LC, fa->tJ, rl, wq, InHCol{fa, 0, wq}, pc);
     for (int q = w; q < rl && w < nwt; q += nwt) {
         if (q == wq) {
             if (lane == 0) fa->tNew[q] = -1;
@@ -1342,6 +1461,10 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
             if (v && idx != pr) {
                 const double x = fabs(val);
                 if (x > cmxl) cmxl = x;
+                if (mc && cl == 2 && q < MC_PREV) { // the one entry that stays: the next search finds it in LDS
+                    mc->e1i[q] = idx;
+                    mc->e1v[q] = val;
+                }
             }
         }
         DEV_CHECK(S, where >= 0);
@@ -1352,7 +1475,8 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
             D.clen[j] = cl - 1;
             D.colmax[j] = cmx;
             fa->tNew[q] = cl - 1;
-            if (BLU_EARLY && q < 64) fa->tMx[q] = cmx;
+            if (q < 64) fa->tMx[q] = cmx;
+            if (mc && cl != 2 && q < MC_PREV) mc->e1i[q] = -1;
             fa->tX[q] = xrj;
             if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
         }
@@ -1360,7 +1484,7 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
     __syncthreads();
     // finalize step: [0] the search of the next pivot, [1] count lists, [2] U row and bookkeeping
     const bool early = BLU_EARLY && split && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl, ew_mcb, ew_fb);
+    if (w == 0 && early) early_search(D, sm, mc, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl, ew_mcb, ew_fb);
     if (w == (early ? 2 : 0)) {
         fast_write_u(D, sm, 0, rl - 1, wq);
         if (lane == 0) {
@@ -1374,9 +1498,13 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, int pr, int pc
     if (w == 1 % nw) {
         if (D.search_rows && lane == 0) list_remove1(D.rflink, D.rblink, pr);
         // the pivot column sits at slot `where` of the row with key -1: it is unlinked as `gone`
-        const int mn = split ? wave_list_append_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, m + 2, fa->kg[0])
-                             : wave_list_move_batch_set(D.cflink, D.cblink, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->kg[0]);
+        const int mn = split ? wave_list_append_set(LC, m, fa->tJ, fa->tNew, rl, m + 2, fa->kg[0], mc ? mc->pFl : nullptr)
+                             : wave_list_move_batch_set(LC, m, fa->tJ, fa->tNew, rl, InHCol{fa, 0, wq}, m + 2, pc, fa->kg[0]);
         if (lane == 0 && mn < sm->min_colnz) sm->min_colnz = mn;
+        if (mc && lane == 0) { // what the next search may reuse (a column that sank below abstol cancels it: dirty)
+            mc->prevValid = split ? 1 : 0;
+            mc->prevBase = 0;
+        }
     }
     __syncthreads();
 }

@@ -16,6 +16,31 @@
 #define BLU_EARLY 1
 #endif
 
+// ---- list heads of the single-matrix kernel in LDS (k_pivot_loop; the batch kernel has none) ---------------
+// Heads and tails of the column count lists 0..MC_HEADS-1 (cflink/cblink[m + k]) live in LDS: every search
+// starts at them and every batched list update ends at them, so each pivot saves two dependent global round
+// trips.  WRITE-THROUGH: global memory is always current.  Everything the general pivot paths do goes straight
+// to global memory; they raise `dirty` and wave 0 reloads the copies before the next search.
+// (A direct-mapped LDS cache of whole line records -- begin, length, capacity, maximum, links -- was built and
+// measured in round 2: 66 % hits on the banded C3 basis, but the per-lane look-ups in the gathers of the pivot
+// set-up and the write-through in every line update cost more than the hits saved: pivot loop +12 %.  Removed.)
+// The same struct carries what the NEXT search may reuse of the pivot just finished ("prev"): 70 % of the
+// candidate columns of a search on a banded basis are columns of the previous pivot row, whose new length,
+// begin and maximum are still in the Fast arrays (slot-indexed: tNew, tB, tMx) and whose membership is still
+// in hCol; with their new forward links (pFl, recorded by the list wave) the walk over them needs no global
+// round trip at all, and a column left with ONE entry by a singleton-column pivot has that entry in e1i/e1v.
+#define MC_HEADS 128
+#define MC_PREV 64 // slots of the previous pivot row that can be reused (rows shorter than this)
+struct Mc {
+    int hf[MC_HEADS], hb[MC_HEADS];
+    int dirty;
+    int prevValid; // 1: the Fast arrays + pFl/e1 describe the columns moved by the previous pivot; slots >= prevBase
+    int prevBase, pad0;
+    int pFl[MC_PREV];
+    int e1i[MC_PREV]; // row index of the single remaining entry, -1 = not known
+    double e1v[MC_PREV];
+};
+
 struct Fast {
     int kind;  // 0 none (general paths), 1 pivot_small, 2 pivot_singleton_col
     int where; // singleton col: slot of the pivot column in the (unswapped) pivot row
@@ -26,11 +51,7 @@ struct Fast {
     // early search: hand-over from the list wave (unlinked runs: predecessor -> first unmoved successor)
     // and the result kept for the next search
     int ewValid, ewNsr;
-#if BLU_EARLY
-    double tMx[64]; // new maximum of the first 64 columns of the pivot row (the early search takes rows < 64 only)
-#else
-    double tMx[1];
-#endif
+    double tMx[64]; // new maximum of the first 64 columns of the pivot row (the next search reuses rows < 64 only)
     // pivot column, pivot at slot 0 (kind 1), with the (begin,len,cap) of each row
     int pcI[PCMAX], prB[PCMAX], prL[PCMAX], prC[PCMAX], rNew[PCMAX], rKept[PCMAX], rDst[PCMAX];
     double pcV[PCMAX];
