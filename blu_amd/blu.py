@@ -320,6 +320,13 @@ class BLU:
         lib().blu_hip_dbg_set_upd_extra.argtypes = [C.c_void_p, C.c_int64]
         lib().blu_hip_dbg_set_upd_extra(self._h, int(n))
 
+    def dbg_set_grid_blocks(self, n):
+        """Workgroups of the chip-wide O(nnz) phases of a single factorize (1 = one workgroup, as inside a batch)."""
+        lib().blu_hip_dbg_set_grid_blocks.argtypes = [C.c_void_p, C.c_int]
+        st = lib().blu_hip_dbg_set_grid_blocks(self._h, int(n))
+        if st != K.OK:
+            raise BluError(st)
+
     def dbg_set_no_fast(self, on=True):
         """Run the general pivot paths only (k_pivot_fast.hip off): A/B of the two implementations."""
         lib().blu_hip_dbg_set_no_fast.argtypes = [C.c_void_p, C.c_int]

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <hip/hip_cooperative_groups.h>
 #include <rocprim/warp/warp_reduce.hpp>
 
 #define BLU_WAVE 64
@@ -317,6 +318,167 @@ __device__ __forceinline__ int block_or_i(int v, int *sh)
     __syncthreads();
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Scopes: the O(nnz) phases around the pivot loop (k_prep, k_setup, k_finish) are written once against
+// this small interface and instantiated twice:
+//   BlockScope  one workgroup per matrix (a batch = a grid of independent workgroups); the sync is
+//               __syncthreads(), scans and counters live in LDS.
+//   GridScope   ONE matrix on a cooperative launch of many workgroups (the single-basis path): the sync
+//               is the grid barrier (agent-scope release / acquire inside), scans combine per-workgroup
+//               partials through global memory, counters are global words.  A single workgroup covers
+//               one CU; these phases are bandwidth-bound and want the chip.
+// Every method must be called by ALL threads of the scope with uniform control flow.
+// ---------------------------------------------------------------------------------------------
+#define SCOPE_MAX_BLOCKS 256
+struct GridWs {                        // global scratch of a GridScope (zeroed by the host before the launch)
+    int part[2][SCOPE_MAX_BLOCKS];
+    long long partll[2][SCOPE_MAX_BLOCKS];
+    int ctr[8];
+};
+struct BlockScope {
+    int *sh;        // 40 ints of LDS
+    long long *shl; // 20 long longs of LDS
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nt() const { return blockDim.x; }
+    __device__ __forceinline__ int wid() const { return wave_id(); }
+    __device__ __forceinline__ int nw() const { return num_waves(); }
+    __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
+    __device__ __forceinline__ int unit() const { return blockIdx.x; } // which matrix of the batch
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ int excl_scan(int v, int *total) { return block_excl_scan_i(v, sh, total); }
+    __device__ __forceinline__ long long sum_ll(long long v) { return block_sum_ll(v, shl); }
+    __device__ __forceinline__ int any(int v) { return block_or_i(v, sh); }
+    __device__ __forceinline__ int *ctr(int k) const { return &sh[34 + k]; } // k = 0..4; zero it, sync, then atomicAdd
+    // maximum / minimum of NON-NEGATIVE doubles over the scope
+    __device__ __forceinline__ double max_d(double v, double *shd)
+    {
+        v = wave_max_d(v);
+        if (lane_id() == 0) shd[wave_id()] = v;
+        __syncthreads();
+        double r = shd[0];
+        for (int w = 1; w < num_waves(); w++) r = r > shd[w] ? r : shd[w];
+        __syncthreads();
+        return r;
+    }
+    __device__ __forceinline__ double min_d(double v, double *shd)
+    {
+        v = -wave_max_d(-v); // (OpMaxD is a plain compare: fine for non-positive values too)
+        if (lane_id() == 0) shd[wave_id()] = v;
+        __syncthreads();
+        double r = shd[0];
+        for (int w = 1; w < num_waves(); w++) r = r < shd[w] ? r : shd[w];
+        __syncthreads();
+        return r;
+    }
+};
+struct GridScope {
+    int *sh;
+    long long *shl;
+    GridWs *g;
+    int parity;
+    __device__ __forceinline__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
+    __device__ __forceinline__ int nt() const { return gridDim.x * blockDim.x; }
+    __device__ __forceinline__ int wid() const { return blockIdx.x * num_waves() + wave_id(); }
+    __device__ __forceinline__ int nw() const { return gridDim.x * num_waves(); }
+    __device__ __forceinline__ bool leader() const { return blockIdx.x == 0 && threadIdx.x == 0; }
+    __device__ __forceinline__ int unit() const { return 0; }
+    __device__ __forceinline__ void sync() { cooperative_groups::this_grid().sync(); }
+    // per-workgroup partials through global memory; two buffers alternate so that one grid barrier per call is enough
+    __device__ __forceinline__ int excl_scan(int v, int *total)
+    {
+        int bt;
+        const int ex = block_excl_scan_i(v, sh, &bt);
+        if (threadIdx.x == 0) __hip_atomic_store(&g->part[parity][blockIdx.x], bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sync();
+        if (wave_id() == 0) {
+            int before = 0, all = 0;
+            for (int b = lane_id(); b < (int)gridDim.x; b += 64) {
+                const int x = __hip_atomic_load(&g->part[parity][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all += x;
+                if (b < (int)blockIdx.x) before += x;
+            }
+            before = wave_sum_i(before);
+            all = wave_sum_i(all);
+            if (lane_id() == 0) {
+                sh[36] = before;
+                sh[37] = all;
+            }
+        }
+        __syncthreads();
+        const int off = sh[36];
+        *total = sh[37];
+        __syncthreads();
+        parity ^= 1;
+        return off + ex;
+    }
+    __device__ __forceinline__ long long sum_ll(long long v)
+    {
+        const long long bs = block_sum_ll(v, shl);
+        if (threadIdx.x == 0) __hip_atomic_store(&g->partll[parity][blockIdx.x], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sync();
+        long long all = 0;
+        if (wave_id() == 0) {
+            for (int b = lane_id(); b < (int)gridDim.x; b += 64)
+                all += __hip_atomic_load(&g->partll[parity][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            all = wave_sum_ll(all);
+            if (lane_id() == 0) shl[17] = all;
+        }
+        __syncthreads();
+        const long long r = shl[17];
+        __syncthreads();
+        parity ^= 1;
+        return r;
+    }
+    __device__ __forceinline__ int any(int v)
+    {
+        int tot;
+        (void)excl_scan(v ? 1 : 0, &tot);
+        return tot != 0;
+    }
+    __device__ __forceinline__ int *ctr(int k) const { return &g->ctr[k]; }
+    // maximum / minimum of NON-NEGATIVE doubles over the scope: they order like their bit patterns
+    __device__ __forceinline__ double max_d(double v, double *shd)
+    {
+        v = wave_max_d(v);
+        if (lane_id() == 0) shd[wave_id()] = v;
+        __syncthreads();
+        double r = shd[0];
+        for (int w = 1; w < num_waves(); w++) r = r > shd[w] ? r : shd[w];
+        __syncthreads();
+        return __longlong_as_double(-min_ll_blocks(-__double_as_longlong(r)));
+    }
+    __device__ __forceinline__ double min_d(double v, double *shd)
+    {
+        v = -wave_max_d(-v);
+        if (lane_id() == 0) shd[wave_id()] = v;
+        __syncthreads();
+        double r = shd[0];
+        for (int w = 1; w < num_waves(); w++) r = r < shd[w] ? r : shd[w];
+        __syncthreads();
+        return __longlong_as_double(min_ll_blocks(__double_as_longlong(r)));
+    }
+    // min over the grid of one value per workgroup (passed by every thread of the workgroup alike)
+    __device__ __forceinline__ long long min_ll_blocks(long long v)
+    {
+        if (threadIdx.x == 0) __hip_atomic_store(&g->partll[parity][blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sync();
+        long long mn = 0x7fffffffffffffffLL;
+        if (wave_id() == 0) {
+            for (int b = lane_id(); b < (int)gridDim.x; b += 64) {
+                const long long x = __hip_atomic_load(&g->partll[parity][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mn = x < mn ? x : mn;
+            }
+            mn = wave_min_ll(mn);
+            if (lane_id() == 0) shl[17] = mn;
+        }
+        __syncthreads();
+        const long long r = shl[17];
+        __syncthreads();
+        parity ^= 1;
+        return r;
+    }
+};
 
 // status helpers: first error wins
 __device__ __forceinline__ void set_error(Scalars *s, int st, int line)

@@ -78,6 +78,8 @@ struct blu_hip {
     int block_threads; // workgroup size of the pivot kernel
     int no_fast;       // debug: disable the LDS fast paths
     int skip_stats;    // 1: do not compute condest / residual_test inside factorize (keys return 0)
+    GridWs *gw;        // scratch of the chip-wide O(nnz) phases (single-basis path)
+    int grid_blocks;   // workgroups of their cooperative launches (0/1: one workgroup, as in a batch)
     std::string err;
     int64_t stop_at;   // debug: -1 off
 };
@@ -249,7 +251,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     want(&D.gwork, 16 * (M + 1));
     want(&D.iw0, M + 2); want(&D.iw1, M + 2); want(&D.iw2, M + 2);
     want(&D.lbeg, M + 1); want(&D.ubeg, M + 1);
-    want(&D.s, 1); want(&h->dD, 1); want(&h->dO, 1);
+    want(&D.s, 1); want(&h->dD, 1); want(&h->dO, 1); want(&h->gw, 1);
     want(&h->O.rowperm, M); want(&h->O.colperm, M); want(&h->O.l_colptr, M + 1); want(&h->O.u_colptr, M + 1);
     want(&h->d_rhs, M); want(&h->d_lhs, M); want(&h->lvl_l, M + 2); want(&h->lvl_u, M + 2);
     ok = ok && dalloc(h, &h->slab, slab_bytes);
@@ -262,6 +264,16 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->dslot = h->dD;
     h->oslot = h->dO;
     h->batch_block = 256;
+    if (ok) { // chip-wide phases: as many workgroups as are certainly co-resident, at most 64 (one per CU of two XCDs' worth)
+        int nb = 0, best = 1 << 30;
+        const void *fns[3] = {(const void *)k_prep_grid, (const void *)k_setup_grid, (const void *)k_finish_grid};
+        for (int k = 0; k < 3; k++) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], 1024, 0) != hipSuccess) nb = 0;
+            best = std::min(best, nb * prop.multiProcessorCount);
+        }
+        h->grid_blocks = std::max(1, std::min(best, 64));
+        if (!prop.cooperativeLaunch) h->grid_blocks = 1;
+    }
     if (ok) ok = hip_ok(h, hipStreamCreate(&h->stream), "hipStreamCreate");
     for (int k = 0; ok && k < 4; k++) ok = hip_ok(h, hipEventCreate(&h->ev[k]), "hipEventCreate");
     if (!ok) {
@@ -672,6 +684,13 @@ extern "C" int blu_hip_dbg_set_batch_block(blu_hip *h, int threads)
 {
     if (!h || threads < 64 || threads > 1024 || (threads & 63)) return BLU_ERROR_INVALID_ARGUMENT;
     h->batch_block = threads;
+    return BLU_OK;
+}
+// workgroups of the chip-wide O(nnz) phases of a single factorize (1: one workgroup, as inside a batch)
+extern "C" int blu_hip_dbg_set_grid_blocks(blu_hip *h, int nblocks)
+{
+    if (!h || nblocks < 1 || nblocks > SCOPE_MAX_BLOCKS) return BLU_ERROR_INVALID_ARGUMENT;
+    h->grid_blocks = nblocks;
     return BLU_OK;
 }
 extern "C" int blu_hip_dbg_set_no_fast(blu_hip *h, int on)

@@ -1,4 +1,5 @@
-// k_finish.hip -- after the pivot loop, one workgroup per matrix:
+// k_finish.hip -- after the pivot loop; written against the Scope interface of blu_dev.h (one workgroup per
+// matrix in a batch: k_finish; the whole chip for a single matrix: k_finish_grid):
 //   k_finish  = the result-defining part of build_factors (src/lu/build_factors.rs:179-223, 395-419)
 //               fused with get_factors (src/get_factors.rs:48-180): completes the permutations and
 //               writes the canonical read-out (L: CSC, unit diagonal first, rows sorted; U: CSC,
@@ -59,46 +60,43 @@ __device__ void wave_sort_segment(long long *key, double *val, int b, int e, int
 
 // Workgroup-wide sort of one long segment [b,e) with distinct keys in [0,m): presence bitmap -> rank.
 // flag/rnk: int[m] scratch, stage_k/stage_v: scratch of >= e-b entries.
-__device__ void block_sort_segment(long long *key, double *val, int b, int e, int m, int *flag, int *rnk,
-                                   int *stage_k, double *stage_v, int *sh)
+template <class Scope>
+__device__ void scope_sort_segment(Scope &sc, long long *key, double *val, int b, int e, int m, int *flag, int *rnk, int *stage_k,
+                                   double *stage_v)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = sc.tid(), nt = sc.nt();
     for (int j = tid; j < m; j += nt) flag[j] = 0;
-    __syncthreads();
+    sc.sync();
     for (int p = b + tid; p < e; p += nt) flag[(int)key[p]] = 1;
-    __syncthreads();
+    sc.sync();
     int base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
         const int j = c0 + tid;
         const int f = j < m ? flag[j] : 0;
         int tot;
-        const int ex = block_excl_scan_i(f, sh, &tot);
+        const int ex = sc.excl_scan(f, &tot);
         if (j < m) rnk[j] = base + ex;
         base += tot;
     }
+    sc.sync();
     for (int p = b + tid; p < e; p += nt) {
         const int k = (int)key[p];
         stage_k[rnk[k]] = k;
         stage_v[rnk[k]] = val[p];
     }
-    __syncthreads();
+    sc.sync();
     for (int p = b + tid; p < e; p += nt) {
         key[p] = stage_k[p - b];
         val[p] = stage_v[p - b];
     }
-    __syncthreads();
+    sc.sync();
 }
 
-__global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
+template <class Scope>
+__device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, Scope &sc, double *shd, int *lds_k, double *lds_v)
 {
-    const DevG D(Ds[blockIdx.x]);
-    const FinishOut &O = Os[blockIdx.x];
     Scalars *S = D.s;
-    __shared__ int sh[40];
-    __shared__ double shd[40];
-    __shared__ int lds_k[16 * WSORT_MAX];
-    __shared__ double lds_v[16 * WSORT_MAX];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = sc.tid(), nt = sc.nt();
     const int m = D.m;
     if (S->status != ST_DONE) return;
     const int rank = S->rank;
@@ -112,16 +110,16 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
             const int e = c0 + tid;
             const int f = (e < m && inv[e] < 0) ? 1 : 0;
             int tot;
-            const int ex = block_excl_scan_i(f, sh, &tot);
+            const int ex = sc.excl_scan(f, &tot);
             if (f) {
                 inv[e] = base + ex;
                 seq[base + ex] = e;
             }
             base += tot;
         }
-        if (base != m && tid == 0) DEV_CHECK(S, false);
+        if (base != m && sc.leader()) DEV_CHECK(S, false);
     }
-    __syncthreads();
+    sc.sync();
     // dependent columns get unit pivots (build_factors.rs:221-223); empty L columns / U rows for them
     for (int k = rank + tid; k < m; k += nt) {
         D.colmax[D.pcol[k]] = 1.0;
@@ -132,13 +130,13 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         O.rowperm[k] = D.prow[k];
         O.colperm[k] = D.pcol[k];
     }
-    __syncthreads();
+    sc.sync();
 
     // ---- L: column k = unit diagonal, then the stage-k column with rows renumbered by pinv and sorted
     // (get_factors.rs:86-113 scatters the row-wise copy in row order, which sorts each column)
     const int l_nz = D.lbeg[rank];
-    if (tid == 0) sh[34] = sh[35] = 0;
-    __syncthreads();
+    if (sc.leader()) *sc.ctr(0) = *sc.ctr(1) = 0;
+    sc.sync();
     for (int k = tid; k <= m; k += nt) O.l_colptr[k] = (long long)D.lbeg[k] + k;
     for (int k = tid; k < m; k += nt) {
         const int b = D.lbeg[k], e = D.lbeg[k + 1];
@@ -149,15 +147,16 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
             O.l_rowidx[ob + 1 + (p - b)] = D.pinv[D.lidx[p]];
             O.l_value[ob + 1 + (p - b)] = D.lval[p];
         }
-        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(&sh[35], 1)] = k; // long: from the top of iw2
-        else if (e - b > 24) D.iw2[atomicAdd(&sh[34], 1)] = k;            // medium: from the bottom
+        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(sc.ctr(1), 1)] = k; // long: from the top of iw2
+        else if (e - b > 24) D.iw2[atomicAdd(sc.ctr(0), 1)] = k;            // medium: from the bottom
         else insertion_sort_pairs(O.l_rowidx, O.l_value, ob + 1, ob + 1 + (e - b));
     }
-    __syncthreads();
+    sc.sync();
     {
-        const int nmed = sh[34], nlong = sh[35];
-        __syncthreads();
-        for (int r = wave_id(); r < nmed; r += num_waves()) {
+        const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc.sync();
+        for (int r = sc.wid(); r < nmed; r += sc.nw()) {
             const int k = D.iw2[r];
             wave_sort_segment(O.l_rowidx, O.l_value, D.lbeg[k] + k + 1, D.lbeg[k + 1] + k + 1, &lds_k[wave_id() * WSORT_MAX],
                               &lds_v[wave_id() * WSORT_MAX]);
@@ -165,27 +164,28 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = D.lbeg[k] + k + 1, e = D.lbeg[k + 1] + k + 1;
-            block_sort_segment(O.l_rowidx, O.l_value, b, e, m, (int *)D.iw0, (int *)D.iw1, (int *)D.tnew, (double *)D.txrj, sh);
+            scope_sort_segment(sc, O.l_rowidx, O.l_value, b, e, m, (int *)D.iw0, (int *)D.iw1, (int *)D.tnew, (double *)D.txrj);
         }
     }
+    sc.sync();
 
     // ---- U: column k collects the entries (stage k', column pcol[k]) of all U rows, ascending k'
     // (get_factors.rs:136-167); entries in columns that never became pivotal are dropped
     // (build_factors.rs:318-337, `qinv[j] < rank`)
     for (int k = tid; k < m; k += nt) D.iw0[k] = 0;
-    __syncthreads();
+    sc.sync();
     for (int k = tid; k < rank; k += nt)
         for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
             const int c = D.qinv[D.uidx[p]];
             if (c < rank) g_atomic_add(&D.iw0[c], 1);
         }
-    __syncthreads();
+    sc.sync();
     int base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
         const int k = c0 + tid;
         const int cnt = k < m ? D.iw0[k] + 1 : 0;
         int tot;
-        const int ex = block_excl_scan_i(cnt, sh, &tot);
+        const int ex = sc.excl_scan(cnt, &tot);
         if (k < m) {
             O.u_colptr[k] = base + ex;
             D.iw1[k] = base + ex; // fill cursor
@@ -193,11 +193,11 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         base += tot;
     }
     const int u_tot = base; // u_nz + m
-    if (tid == 0) {
+    if (sc.leader()) {
         O.u_colptr[m] = u_tot;
-        sh[34] = sh[35] = 0;
+        *sc.ctr(0) = *sc.ctr(1) = 0;
     }
-    __syncthreads();
+    sc.sync();
     for (int k = tid; k < rank; k += nt)
         for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
             const int c = D.qinv[D.uidx[p]];
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
                 O.u_value[pos] = D.uval[p];
             }
         }
-    __syncthreads();
+    sc.sync();
     double pmin = INFINITY, pmax = 0.0;
     for (int k = tid; k < m; k += nt) {
         const int b = (int)O.u_colptr[k], e = b + D.iw0[k];
@@ -216,15 +216,16 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         O.u_value[e] = piv;
         pmin = fmin(pmin, fabs(piv));
         pmax = fmax(pmax, fabs(piv));
-        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(&sh[35], 1)] = k;
-        else if (e - b > 24) D.iw2[atomicAdd(&sh[34], 1)] = k;
+        if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(sc.ctr(1), 1)] = k;
+        else if (e - b > 24) D.iw2[atomicAdd(sc.ctr(0), 1)] = k;
         else insertion_sort_pairs(O.u_rowidx, O.u_value, b, e);
     }
-    __syncthreads();
+    sc.sync();
     {
-        const int nmed = sh[34], nlong = sh[35];
-        __syncthreads();
-        for (int r = wave_id(); r < nmed; r += num_waves()) {
+        const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc.sync();
+        for (int r = sc.wid(); r < nmed; r += sc.nw()) {
             const int k = D.iw2[r];
             const int b = (int)O.u_colptr[k];
             wave_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], &lds_k[wave_id() * WSORT_MAX], &lds_v[wave_id() * WSORT_MAX]);
@@ -232,28 +233,40 @@ __global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = (int)O.u_colptr[k];
-            block_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], m, (int *)D.iw1, (int *)D.tnewr, (int *)D.tnew, (double *)D.txrj, sh);
+            // (the segment's own length lives in iw0, which the sort must not use as scratch: iw1 / tnewr / tnew / txrj)
+            scope_sort_segment(sc, O.u_rowidx, O.u_value, b, b + D.iw0[k], m, (int *)D.iw1, (int *)D.tnewr, (int *)D.tnew, (double *)D.txrj);
         }
     }
-    // min / max pivot (build_factors.rs:403-419)
-    pmin = wave_max_d(-pmin); // max of negatives = -min
-    pmax = wave_max_d(pmax);
-    if (lane_id() == 0) {
-        shd[wave_id()] = pmin;
-        shd[16 + wave_id()] = pmax;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double a = shd[0], b = shd[16];
-        for (int w = 1; w < num_waves(); w++) {
-            a = a > shd[w] ? a : shd[w];
-            b = b > shd[16 + w] ? b : shd[16 + w];
-        }
-        S->min_pivot = -a;
-        S->max_pivot = b;
+    // min / max pivot (build_factors.rs:403-419): |pivots| are non-negative, so they order like their bit patterns
+    const double amin = sc.min_d(pmin, shd), amax = sc.max_d(pmax, shd);
+    if (sc.leader()) {
+        S->min_pivot = amin;
+        S->max_pivot = amax;
         S->l_nz = l_nz;
         S->u_nz = u_tot - m;
     }
+}
+__global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    __shared__ double shd[40];
+    __shared__ int lds_k[16 * WSORT_MAX];
+    __shared__ double lds_v[16 * WSORT_MAX];
+    const DevG D(Ds[blockIdx.x]);
+    BlockScope sc{sh, shl};
+    finish_body(D, Os[blockIdx.x], sc, shd, lds_k, lds_v);
+}
+__global__ void __launch_bounds__(1024) k_finish_grid(DevLU *Ds, FinishOut *Os, GridWs *gw)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    __shared__ double shd[40];
+    __shared__ int lds_k[16 * WSORT_MAX];
+    __shared__ double lds_v[16 * WSORT_MAX];
+    const DevG D(Ds[0]);
+    GridScope sc{sh, shl, gw, 0};
+    finish_body(D, Os[0], sc, shd, lds_k, lds_v);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,4 +1,6 @@
-// k_prep.hip -- O(nnz) phases in front of the pivot loop, one workgroup per matrix.
+// k_prep.hip -- O(nnz) phases in front of the pivot loop.  Written once against the Scope interface of
+// blu_dev.h: one workgroup per matrix in a batch (k_prep, k_setup), the whole chip for a single matrix
+// (k_prep_grid, k_setup_grid: cooperative launch, grid barriers between the passes).
 //
 //   k_prep   = singletons()  (src/lu/singletons.rs:81-264): validate B, build the row-wise copy,
 //              peel singleton columns/rows (without cascade: reference defect D1)
@@ -14,14 +16,16 @@
 // keys[e] < 0 : element is not inserted.  Equivalent to `for e in 0..n { list_add(e, keys[e]) }`
 // (list.rs:54-77).  Returns the minimum key > 0 seen (or big).
 // ---------------------------------------------------------------------------------------------
-__device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, int big)
+// The lists are independent of each other, so the waves of the scope share them out: wave `part` of `nparts`
+// builds the lists with key % nparts == part (every wave scans all elements; the keys are read coalesced).
+__device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, int big, int part, int nparts)
 {
     const int lane = lane_id();
     int minkey = big;
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int e = c0 + lane;
         int key = e < n ? keys[e] : -1;
-        bool act = key >= 0;
+        bool act = key >= 0 && key % nparts == part;
         if (act && key > 0) minkey = min(minkey, key);
         unsigned long long active = __ballot(act);
         while (active) {
@@ -50,13 +54,10 @@ __device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, 
 // ---------------------------------------------------------------------------------------------
 // k_prep
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
+template <class Scope> __device__ __forceinline__ void prep_body(const DevG &D, Scope &sc)
 {
-    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
-    __shared__ int sh[40];
-    __shared__ long long shl[20];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = sc.tid(), nt = sc.nt();
     const int m = D.m;
     if (S->status != ST_RUNNING) return;
 
@@ -74,35 +75,35 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         }
         // the chunk total in 64 bits FIRST: up to 1024 lengths of up to 2^31-1 each (columns may overlap) can wrap
         // a 32-bit scan, and a wrapped total would pass the range check below
-        const long long tot64 = block_sum_ll((long long)len, shl);
+        const long long tot64 = sc.sum_ll((long long)len);
         if ((long long)base + tot64 > 0x7fffffffLL) {
             bad = 1;
             break; // (uniform: every thread sees the same total)
         }
         int tot;
-        int ex = block_excl_scan_i(len, sh, &tot);
+        int ex = sc.excl_scan(len, &tot);
         if (j < m) D.bc_ptr[j] = base + ex;
         base += tot;
     }
-    bad = block_or_i(bad, sh);
+    bad = sc.any(bad);
     if (bad) {
-        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        if (sc.leader()) set_error(S, ST_INVALID_ARG, __LINE__);
         return;
     }
     const int b_nz = base;
-    if (tid == 0) {
+    if (sc.leader()) {
         D.bc_ptr[m] = b_nz;
         S->matrix_nz = b_nz;
     }
     if (b_nz > D.nzcap) { // host sized the packed copies too small (overlapping columns): ask for more
-        if (tid == 0) {
+        if (sc.leader()) {
             S->need = b_nz;
             set_error(S, ST_NEED_CW, __LINE__);
         }
         return;
     }
     for (int i = tid; i < m; i += nt) D.iw0[i] = 0;
-    __syncthreads();
+    sc.sync();
 
     // ---- count nz per row, check indices, pack columns (singletons.rs:152-173)
     for (int j = tid; j < m; j += nt) {
@@ -120,9 +121,9 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             put++;
         }
     }
-    bad = block_or_i(bad, sh);
+    bad = sc.any(bad); // (a grid barrier in the wide scope: the row counts of every workgroup are complete behind it)
     if (bad) {
-        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        if (sc.leader()) set_error(S, ST_INVALID_ARG, __LINE__);
         return;
     }
 
@@ -132,15 +133,15 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         const int i = c0 + tid;
         const int cnt = i < m ? D.iw0[i] : 0;
         int tot;
-        int ex = block_excl_scan_i(cnt, sh, &tot);
+        int ex = sc.excl_scan(cnt, &tot);
         if (i < m) {
             D.bt_ptr[i] = base + ex;
             D.iw1[i] = base + ex; // fill cursor
         }
         base += tot;
     }
-    if (tid == 0) D.bt_ptr[m] = base;
-    __syncthreads();
+    if (sc.leader()) D.bt_ptr[m] = base;
+    sc.sync();
 
     // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
     // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
@@ -152,14 +153,13 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             D.bt_val[p] = D.bc_val[pos];
         }
     }
-    __syncthreads();
-    // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the workgroup
-    if (tid == 0) sh[34] = 0; // number of long rows
-    __syncthreads();
+    if (sc.leader()) *sc.ctr(0) = 0; // number of long rows
+    sc.sync();
+    // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the whole scope
     for (int i = tid; i < m; i += nt) {
         const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
         if (e - b > 48) {
-            const int k = atomicAdd(&sh[34], 1);
+            const int k = atomicAdd(sc.ctr(0), 1);
             D.iw2[k] = i; // list of long rows (order irrelevant)
             continue;
         }
@@ -178,27 +178,28 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         for (int p = b + 1; p < e; p++)
             if (D.bt_idx[p] == D.bt_idx[p - 1]) bad = 1; // duplicate (singletons.rs:195-197)
     }
-    __syncthreads();
-    const int nlong = sh[34];
-    __syncthreads();
+    sc.sync();
+    const int nlong = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sc.sync();
     for (int r = 0; r < nlong; r++) {
         const int i = D.iw2[r];
         const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
         // bitmap of columns present in row i -> rank of each column -> ordered rewrite
         for (int j = tid; j < m; j += nt) D.iw0[j] = 0;
-        __syncthreads();
+        sc.sync();
         for (int p = b + tid; p < e; p += nt)
             if (g_atomic_add(&D.iw0[D.bt_idx[p]], 1) != 0) bad = 1; // duplicate
-        __syncthreads();
+        sc.sync();
         int rb = 0;
         for (int c0 = 0; c0 < m; c0 += nt) {
             const int j = c0 + tid;
             const int f = j < m ? (D.iw0[j] ? 1 : 0) : 0;
             int tot;
-            int ex = block_excl_scan_i(f, sh, &tot);
+            int ex = sc.excl_scan(f, &tot);
             if (j < m) D.iw1[j] = rb + ex; // rank of column j inside the row
             rb += tot;
         }
+        sc.sync();
         // stage (idx,val) in the column arena's scratch-free tail: use tnew/txrj (m entries each)
         for (int p = b + tid; p < e; p += nt) {
             const int j = D.bt_idx[p];
@@ -206,16 +207,16 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             D.tnew[rk] = j;
             D.txrj[rk] = D.bt_val[p];
         }
-        __syncthreads();
+        sc.sync();
         for (int p = b + tid; p < e; p += nt) {
             D.bt_idx[p] = D.tnew[p - b];
             D.bt_val[p] = D.txrj[p - b];
         }
-        __syncthreads();
+        sc.sync();
     }
-    bad = block_or_i(bad, sh);
+    bad = sc.any(bad);
     if (bad) {
-        if (tid == 0) set_error(S, ST_INVALID_ARG, __LINE__);
+        if (sc.leader()) set_error(S, ST_INVALID_ARG, __LINE__);
         return;
     }
 
@@ -224,11 +225,11 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         D.pinv[i] = -1;
         D.qinv[i] = -1;
     }
-    if (tid == 0) {
+    if (sc.leader()) {
         D.lbeg[0] = 0;
         D.ubeg[0] = 0;
     }
-    __syncthreads();
+    sc.sync();
     int rank = 0, lused = 0, uused = 0;
     const double abstol = D.abstol;
     for (int phase = 0; phase < 2; phase++) {
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         // smallest singleton row).  In queue order (ascending index, singletons.rs:318-329) the first
         // acceptable one eliminates the line and empties the others (:337-339, :352-355).
         for (int i = tid; i < m; i += nt) D.iw0[i] = 0x7fffffff;
-        __syncthreads();
+        sc.sync();
         for (int e = tid; e < m; e += nt) {
             if (cols) {
                 const int j = e;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
                 }
             }
         }
-        __syncthreads();
+        sc.sync();
         // ranks of the winners in ascending index
         int nwin = 0;
         for (int c0 = 0; c0 < m; c0 += nt) {
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
                 }
             }
             int tot;
-            int ex = block_excl_scan_i(win, sh, &tot);
+            int ex = sc.excl_scan(win, &tot);
             if (win) {
                 const int r = rank + nwin + ex;
                 const int i = cols ? other : e, j = cols ? e : other;
@@ -291,12 +292,12 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
             }
             nwin += tot;
         }
-        __syncthreads();
+        sc.sync();
         for (int r = rank + tid; r < rank + nwin; r += nt) {
             D.pinv[D.prow[r]] = r;
             D.qinv[D.pcol[r]] = r;
         }
-        __syncthreads();
+        sc.sync();
         // factor entries of the new stages, in stage order
         int put0 = cols ? uused : lused;
         for (int c0 = 0; c0 < nwin; c0 += nt) {
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
                 }
             }
             int tot;
-            int ex = block_excl_scan_i(cnt, sh, &tot);
+            int ex = sc.excl_scan(cnt, &tot);
             if (r < rank + nwin) {
                 int put = put0 + ex;
                 const bool fits = cols ? (put0 + tot <= D.ucap) : (put0 + tot <= D.lcap);
@@ -351,34 +352,47 @@ __global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
         }
         if (cols) uused = put0; else lused = put0;
         rank += nwin;
-        __syncthreads();
+        sc.sync();
     }
     // singletons.rs:135-150 guarantees l_mem, u_mem >= nnz(B) up front; here L/U are sized by the host
     if (uused > D.ucap || lused > D.lcap) {
-        if (tid == 0) {
+        if (sc.leader()) {
             S->need = max(uused, lused);
             set_error(S, uused > D.ucap ? ST_NEED_U : ST_NEED_L, __LINE__);
         }
         return;
     }
-    if (tid == 0) {
+    if (sc.leader()) {
         S->rank = rank;
         S->rank0 = rank;
         S->lused = lused;
         S->uused = uused;
     }
 }
+__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const DevG D(Ds[blockIdx.x]);
+    BlockScope sc{sh, shl};
+    prep_body(D, sc);
+}
+__global__ void __launch_bounds__(1024) k_prep_grid(DevLU *Ds, GridWs *gw)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const DevG D(Ds[0]);
+    GridScope sc{sh, shl, gw, 0};
+    prep_body(D, sc);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_setup = setup_bump (setup_bump.rs:55-264)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
+template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D, Scope &sc)
 {
-    const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
-    __shared__ int sh[40];
-    __shared__ long long shl[20];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = sc.tid(), nt = sc.nt();
     const int m = D.m;
     if (S->status != ST_RUNNING) return;
     const int rank = S->rank;
@@ -410,7 +424,7 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
             }
         }
         int tot;
-        int ex = block_excl_scan_i(cap, sh, &tot);
+        int ex = sc.excl_scan(cap, &tot);
         if (j < m) {
             D.iw0[j] = key;
             D.cbeg[j] = key > 0 ? base + ex : 0;
@@ -419,17 +433,17 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
             if (key >= 0) D.colmax[j] = cmx;
         }
         if ((long long)base + tot > (long long)D.carena_cap) {
-            if (tid == 0) {
+            if (sc.leader()) {
                 S->need = base + tot;
                 set_error(S, ST_NEED_CW, __LINE__);
             }
-            return; // uniform: base/tot are workgroup-uniform
+            return; // uniform: base/tot are the same for every thread of the scope
         }
         base += tot;
     }
     const int cused = base;
-    dropped_nz = block_sum_ll(dropped_nz, shl);
-    __syncthreads();
+    dropped_nz = sc.sum_ll(dropped_nz);
+    sc.sync();
     for (int j = tid; j < m; j += nt) {
         if (D.iw0[j] <= 0) continue;
         int put = D.cbeg[j];
@@ -453,7 +467,7 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
             cap = rnz + stretch_of(stretch, rnz) + pad;
         }
         int tot;
-        int ex = block_excl_scan_i(cap, sh, &tot);
+        int ex = sc.excl_scan(cap, &tot);
         if (i < m) {
             D.iw1[i] = key;
             D.rbeg[i] = key >= 0 ? base + ex : 0;
@@ -461,7 +475,7 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
             D.rcap[i] = cap;
         }
         if ((long long)base + tot > (long long)D.rarena_cap) {
-            if (tid == 0) {
+            if (sc.leader()) {
                 S->need = base + tot;
                 set_error(S, ST_NEED_RW, __LINE__);
             }
@@ -470,7 +484,7 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
         base += tot;
     }
     const int rused = base;
-    __syncthreads();
+    sc.sync();
     for (int i = tid; i < m; i += nt) {
         if (D.iw1[i] < 0) continue;
         int put = D.rbeg[i];
@@ -494,20 +508,19 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
         D.colmark[e] = 0;
         D.iw2[e] = 0;
     }
-    __syncthreads();
-    const int w = wave_id();
-    if (w == 0) {
-        int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2);
-        if (lane_id() == 0) S->min_colnz = mn; // list_init sets min_list = max(1, nlist) = m + 2 (list.rs:48-50)
-    } else if (w == 1 || num_waves() == 1) {
-        int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2);
-        if (lane_id() == 0) S->min_rownz = mn;
+    if (sc.leader()) { // list_init sets min_list = max(1, nlist) = m + 2 (list.rs:48-50)
+        S->min_colnz = m + 2;
+        S->min_rownz = m + 2;
     }
-    if (num_waves() == 1 && w == 0) {
-        int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2);
-        if (lane_id() == 0) S->min_rownz = mn;
+    sc.sync();
+    { // every wave of the scope builds its share of the lists (keys == wave index modulo the number of waves)
+        const int part = sc.wid(), nparts = sc.nw();
+        int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2, part, nparts);
+        if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_colnz, mn);
+        mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2, part, nparts);
+        if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_rownz, mn);
     }
-    if (tid == 0) {
+    if (sc.leader()) {
         const long long l_nz = S->lused, u_nz = S->uused;
         S->bump_nz = S->matrix_nz - l_nz - u_nz - rank - dropped_nz; // setup_bump.rs:89, :155
         S->bump_size = m - rank;
@@ -517,4 +530,20 @@ __global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
         S->pivot_col = -1;
         S->rankdef = 0;
     }
+}
+__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const DevG D(Ds[blockIdx.x]);
+    BlockScope sc{sh, shl};
+    setup_body(D, sc);
+}
+__global__ void __launch_bounds__(1024) k_setup_grid(DevLU *Ds, GridWs *gw)
+{
+    __shared__ int sh[40];
+    __shared__ long long shl[20];
+    const DevG D(Ds[0]);
+    GridScope sc{sh, shl, gw, 0};
+    setup_body(D, sc);
 }
