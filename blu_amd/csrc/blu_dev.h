@@ -350,6 +350,14 @@ struct BlockScope {
     __device__ __forceinline__ long long sum_ll(long long v) { return block_sum_ll(v, shl); }
     __device__ __forceinline__ int any(int v) { return block_or_i(v, sh); }
     __device__ __forceinline__ int *ctr(int k) const { return &sh[34 + k]; } // k = 0..4; zero it, sync, then atomicAdd
+    // which share of the column / row count lists this wave builds (k_setup): wave 0 all column lists, wave 1 all row lists
+    __device__ __forceinline__ void list_roles(int &part, int &nparts, bool &cols, bool &rows) const
+    {
+        part = 0;
+        nparts = 1;
+        cols = wave_id() == 0;
+        rows = num_waves() == 1 ? wave_id() == 0 : wave_id() == 1;
+    }
     // maximum / minimum of NON-NEGATIVE doubles over the scope
     __device__ __forceinline__ double max_d(double v, double *shd)
     {
@@ -437,6 +445,23 @@ struct GridScope {
         return tot != 0;
     }
     __device__ __forceinline__ int *ctr(int k) const { return &g->ctr[k]; }
+    // one builder wave per workgroup; the first half of the workgroups share out the column lists (by key modulo
+    // their number), the second half the row lists.  Every builder scans all keys, so few builders beat many.
+    __device__ __forceinline__ void list_roles(int &part, int &nparts, bool &cols, bool &rows) const
+    {
+        const int G = gridDim.x, b = blockIdx.x, half = G / 2;
+        if (G == 1) {
+            part = 0;
+            nparts = 1;
+            cols = wave_id() == 0;
+            rows = wave_id() == 1;
+            return;
+        }
+        nparts = half;
+        part = b < half ? b : b - half;
+        cols = wave_id() == 0 && b < half;
+        rows = wave_id() == 0 && b >= half && b < 2 * half;
+    }
     // maximum / minimum of NON-NEGATIVE doubles over the scope: they order like their bit patterns
     __device__ __forceinline__ double max_d(double v, double *shd)
     {

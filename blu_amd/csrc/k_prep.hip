@@ -513,12 +513,18 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         S->min_rownz = m + 2;
     }
     sc.sync();
-    { // every wave of the scope builds its share of the lists (keys == wave index modulo the number of waves)
-        const int part = sc.wid(), nparts = sc.nw();
-        int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2, part, nparts);
-        if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_colnz, mn);
-        mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2, part, nparts);
-        if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_rownz, mn);
+    { // the builder waves of the scope share out the lists (Scope::list_roles)
+        int part, nparts;
+        bool cols, rows;
+        sc.list_roles(part, nparts, cols, rows);
+        if (cols) {
+            const int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2, part, nparts);
+            if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_colnz, mn);
+        }
+        if (rows) {
+            const int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2, part, nparts);
+            if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_rownz, mn);
+        }
     }
     if (sc.leader()) {
         const long long l_nz = S->lused, u_nz = S->uused;
