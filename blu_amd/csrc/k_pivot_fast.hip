@@ -1423,6 +1423,12 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
 
 // ------------------------------------------------------------------------------------------------
 // kind 2: pivot_singleton_col (pivot.rs:928-1025), whole workgroup
+// (Round 2 also built this pivot kind -- half of all pivots, in long runs -- as a single-wave route with search
+// and elimination fused, no workgroup barrier, the pivot row in the registers of wave 0 and a register stash
+// from one pivot to the next.  Bit-identical, and no faster: a lone wave issues one instruction every ~7 cycles,
+// and the ~2 000 instructions of such a pivot -- column entries 4 600 cycles, batched list update 4 300, the
+// dependent look-ups of the search 3 300, stores and bookkeeping 1 800 -- cost the 6.8 us that the sixteen-wave
+// route with its three barriers costs: 820 -> 885 ms at C3.  Not kept.)
 // ------------------------------------------------------------------------------------------------
 template <bool BATCH>
 __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr, int pc, int rl, int wq, long long &ew_mcb, int &ew_fb)
