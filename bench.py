@@ -37,7 +37,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--mods", type=int, default=1000, help="C5: column modifications per step")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=1280, help="bases in flight for the secondary throughput measurement (0 = skip)")
@@ -139,6 +140,66 @@ def _traffic_record(kernel):
     return rec.get("kernels", {}).get(kernel)
 
 
+def bench_c5(args):
+    """BASELINE.json configs[4]: Forrest-Tomlin update + sparse re-solve loop on the 100k basis.  A step = `--mods`
+    column modifications, each: solve_for_update (transposed, solution wanted = the re-solve of the row system),
+    solve_for_update (forward, solution wanted = the re-solve with the incoming column), update.  The factorize
+    in front of every step is outside the timed region.  Secondary metric (not the headline): modifications/s,
+    and the algorithmic byte rate of the solves, 16*(l_flops + u_flops + r_flops) + 16*nz(lhs)."""
+    import numpy as np
+    import blu_amd
+    from blu_amd import keys as K
+    from blu_amd.matrices import CONFIGS
+    from blu_amd.workloads import column_modifications
+    c = CONFIGS["C3"]
+    cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+    m = c["m"]
+    h = blu_amd.BLU(m, len(ri))
+    mods = list(column_modifications(cp, ri, args.mods, c["offscale"]))
+    tot_t, done, skipped, nzl, flops = 0.0, 0, 0, 0, 0.0
+    for step in range(args.warmup + args.steps):
+        assert h.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+        f0 = sum(h.stat(k) for k in (K.STAT_L_FLOPS, K.STAT_U_FLOPS, K.STAT_R_FLOPS))
+        t0 = time.perf_counter()
+        d = s_ = nz = 0
+        for j, rows, vals in mods:
+            assert h.solve_for_update([j], None, "T") == K.OK
+            nz += h.nzlhs
+            assert h.solve_for_update(rows, vals, "N") == K.OK
+            nz += h.nzlhs
+            xtbl = h.lhs[j]
+            if abs(xtbl) < 1e-3:  # the replacement would make the basis (nearly) singular: not applied
+                s_ += 1
+                continue
+            st = h.update(xtbl)
+            if st == K.ERROR_SINGULAR_UPDATE:
+                s_ += 1
+                continue
+            assert st == K.OK, st
+            d += 1
+        el = time.perf_counter() - t0
+        if step >= args.warmup:
+            tot_t += el
+            done += d
+            skipped += s_
+            nzl += nz
+            flops += sum(h.stat(k) for k in (K.STAT_L_FLOPS, K.STAT_U_FLOPS, K.STAT_R_FLOPS)) - f0
+    nmod = args.steps * len(mods)
+    gbs = (16.0 * flops + 16.0 * nzl) / tot_t / 1e9
+    out = {"metric": "Forrest-Tomlin update + sparse re-solve: column modifications/s, 100k x 100k basis", "value": nmod / tot_t,
+           "unit": "modifications/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tot_t / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "C5: C3 basis (m=%d, nnz=%d) + %d column modifications per step (blu_amd/workloads.py, SplitMix64 seed 99): "
+                                  "2 x solve_for_update with solution + update each" % (m, len(ri), len(mods)),
+                      "updates_applied_per_step": done / args.steps, "not_applied_per_step": skipped / args.steps,
+                      "nforrest_end": h.stat(K.STAT_NFORREST), "pivot_error_last": h.stat(K.STAT_PIVOT_ERROR)},
+           "roofline": {"bound": "hbm", "kernel": "k_solve_upd + k_update (one wave each: dependent pointer chases)", "achieved": gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes": "16*(l_flops+u_flops+r_flops) + 16*nz(lhs)"}}
+    print(json.dumps(out), flush=True)
+    return out
+
+
 def rank_main(args, backend=None, device=None):
     """What one rank does.  backend: the module that provides BLU / gen_lp_basis / factorize_batch (blu_amd on
     the GPU; tests/test_shard_gloo.py passes a CPU stand-in to execute the N > 1 code path -- seeds, barriers,
@@ -227,6 +288,18 @@ def rank_main(args, backend=None, device=None):
         val = h.stat(key)
         if val == val and val > 0:
             phases[name + "_ms"] = 1e3 * val
+    # the O(nnz) phases: algorithmic bytes with the reference's 16-byte (index, value) entries and 8-byte integers
+    # (SURVEY.md 8d): k_prep reads B and writes the row-wise copy; k_setup reads it and writes both files of the
+    # bump plus the count lists; k_finish reads the stage-ordered factors and writes the canonical ones
+    bump_nz = h.stat(K.STAT_BUMP_NZ)
+    o_bytes = {"k_prep": 16.0 * (nnz + m) + 16.0 * nnz, "k_setup": 16.0 * nnz + 24.0 * bump_nz + 32.0 * (2 * m + 2),
+               "k_finish": 16.0 * (l_nz + u_nz) + 16.0 * (l_nz + u_nz + 2 * m) + 16.0 * m}
+    o_rows = {}
+    for name in o_bytes:
+        if name + "_ms" in phases:
+            g = o_bytes[name] / (1e-3 * phases[name + "_ms"]) / 1e9
+            o_rows[name] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": o_bytes[name], "ms": phases[name + "_ms"]}
     out = {
         "metric": "factorize nnz/s + achieved HBM GB/s, %dk x %dk %d-nnz/col basis" % (m // 1000, m // 1000, c["k"]),
         "value": total_nnz * args.steps / elapsed,
@@ -256,6 +329,7 @@ def rank_main(args, backend=None, device=None):
         "achieved_GBs_whole_factorize": bytes_all * args.steps / elapsed / 1e9,
         "device_ms_per_step": 1e3 * t_dev / args.steps,
         "phases_last_step": phases,
+        "roofline_onnz_kernels": o_rows,
     }
     if args.batch > 0 and not stub:
         out["batched"] = batched_throughput(args, c, dev, local_rank, world, backend)
@@ -275,6 +349,11 @@ def rank_main(args, backend=None, device=None):
 
 def main():
     args = parse_args()
+    if args.config == "C5":
+        if args.gpus != 1:
+            raise SystemExit("bench.py: --config C5 is a single-GPU workload")
+        bench_c5(args)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         # No launcher: start one as a child process, before this process has touched the GPU in any way
         # (nothing of torch.cuda or libblu_hip has been imported or called so far), and hand its return code on.

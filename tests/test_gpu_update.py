@@ -116,3 +116,46 @@ def test_maximum_updates_and_storage_growth(blu, oracle):
     log = U.run_updates(g, cols, m, 400, np.random.default_rng(11), check_every=5, stop_on_max=True, twin=o)
     assert log["hit_maximum_updates"] and int(g.stat(K.STAT_NFORREST)) == m, log
     assert log["max_residual"] <= 1e-7, log
+
+
+def test_config_c5_column_replacement_stream(blu, oracle):
+    """BASELINE.json configs[4] (the workload of `bench.py --config C5`) at the full 100k size: the first 150
+    modifications of the stream in lockstep with the CPU twin (bit-identical re-solves, identical update kinds and
+    counters), then the modified basis is checked by backward error of dense and sparse solves."""
+    from blu_amd.matrices import CONFIGS
+    from blu_amd.workloads import column_modifications
+    c = CONFIGS["C3"]
+    cp, ri, v = oracle.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
+    m = c["m"]
+    g = blu.BLU(m, len(ri))
+    o = oracle.OracleBLU(m, 16 * len(ri))
+    assert g.factorize(cp[:-1], cp[1:], ri, v) == o.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    cols = U.columns_of(cp, ri, v)
+    done = 0
+    for j, rows, vals in column_modifications(cp, ri, 150, c["offscale"]):
+        a = U._sfu(g, [j], None, "T")
+        U._same(a, U._sfu(o, [j], None, "T"), ("T", j))
+        a = U._sfu(g, rows, vals, "N")
+        U._same(a, U._sfu(o, rows, vals, "N"), ("N", j))
+        xtbl = a[2][j]
+        if abs(xtbl) < 1e-3:
+            continue
+        st = g.update(xtbl)
+        assert st == o.update(xtbl) and st in (K.OK, K.ERROR_SINGULAR_UPDATE)
+        if st == K.OK:
+            cols[j] = (rows.astype(np.int64), vals)
+            done += 1
+            for key in (K.STAT_NFORREST, K.STAT_NSYMPERM_TOTAL, K.STAT_DEV_NUNSYMPERM_TOTAL, K.STAT_PIVOT_ERROR, K.STAT_U_NZ, K.STAT_R_NZ):
+                assert g.stat(key) == o.stat(key), (key, j)
+    assert done >= 100 and g.stat(K.STAT_NUPDATE) == done
+    B = U.matrix_of(cols, m)
+    b = np.random.default_rng(3).standard_normal(m)
+    for trans, A in (("N", B), ("T", B.T)):
+        x = g.solve_dense(b, trans)
+        assert np.array_equal(x, o.solve_dense(b, trans))
+        assert U.backward_error(A, x, b) < 1e-10
+        ir, xr = np.array([17, 40000, 99999]), np.array([1.0, -2.0, 0.5])
+        assert g.solve_sparse(ir, xr, trans) == K.OK
+        bs = np.zeros(m)
+        bs[ir] = xr
+        assert U.backward_error(A, g.lhs, bs) < 1e-10
