@@ -181,6 +181,34 @@ __device__ __forceinline__ int solve_triangular(const G &g, int nz_symb, const i
     return nz;
 }
 
+// The sequential branches of the sparse solves (lu/solve_sparse.rs:159-179, 307-334): a sweep over the whole
+// pivot sequence, k descending, that does something only where the vector is nonzero.  One dependent global load
+// per k is ~1 us on a lone wave -- 0.1 s for m = 100 000 even if the vector is nearly empty -- so the sweep takes
+// 64 sequence positions at a time: their entries are loaded together, the zero ones cost nothing, and after
+// every step that was worked the remaining positions of the chunk are re-read (the step may have filled them).
+// The order of the steps, and with it every sum, is the reference's.
+//   seq(k)      vector index of sequence position k
+//   step(k, i, x)  work one position whose entry x = vec[i] is nonzero (uniform arguments); may modify vec
+template <class Seq, class Step>
+__device__ __forceinline__ void sweep_nonzeros_desc(int len, const double *vec, Seq seq, Step step)
+{
+    const int lane = lane_id();
+    for (int k0 = len - 1; k0 >= 0; k0 -= 64) {
+        const int k = k0 - lane;
+        const int i = k >= 0 ? seq(k) : 0;
+        double x = k >= 0 ? vec[i] : 0.0;
+        unsigned long long todo = __ballot(x != 0.0);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1; // lowest lane = highest position
+            step(k0 - l, wave_bcast_i(i, l), wave_bcast_d(x, l));
+            wave_mem_sync();
+            x = k >= 0 ? vec[i] : 0.0;
+            todo = __ballot(x != 0.0) & ~((2ull << l) - 1ull);
+            if (l == 63) todo = 0ull;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, SparseWs W, int nrhs, const int *irhs, const double *xrhs,
                                                      int trans, int marker, int nz_sparse)
 {
@@ -223,26 +251,21 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
             const int nin = nz;
             (void)nin;
             nz = 0;
-            for (int k = m - 1; k >= 0; k--) {
-                const int ipivot = D.prow[k];
-                const double x = W.xlhs[ipivot];
-                if (x != 0.0) {
-                    const int b = GT.begin(ipivot), e = GT.end(ipivot);
-                    for (int p = b + lane; p < e; p += 64) {
-                        const int i = GT.node(p);
-                        W.xlhs[i] = __dsub_rn(W.xlhs[i], __dmul_rn(x, GT.val(p)));
-                    }
-                    l_flops += e - b;
-                    wave_mem_sync();
-                    if (fabs(x) > droptol) {
-                        if (lane == 0) W.ilhs[nz] = ipivot;
-                        nz++;
-                    } else if (lane == 0) {
-                        W.xlhs[ipivot] = 0.0;
-                    }
-                    wave_mem_sync();
+            sweep_nonzeros_desc(m, W.xlhs, [&](int k) { return D.prow[k]; }, [&](int, int ipivot, double x) {
+                const int b = GT.begin(ipivot), e = GT.end(ipivot);
+                for (int p = b + lane; p < e; p += 64) {
+                    const int i = GT.node(p);
+                    W.xlhs[i] = __dsub_rn(W.xlhs[i], __dmul_rn(x, GT.val(p)));
                 }
-            }
+                l_flops += e - b;
+                wave_mem_sync();
+                if (fabs(x) > droptol) {
+                    if (lane == 0) W.ilhs[nz] = ipivot;
+                    nz++;
+                } else if (lane == 0) {
+                    W.xlhs[ipivot] = 0.0;
+                }
+            });
         }
     } else {
         // ---- forward system (solve_sparse.rs:180-346): L, then U
@@ -284,29 +307,24 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         } else { // sequential solve with U (:307-334)
             branch = 2;
             nz = 0;
-            for (int k = m - 1; k >= 0; k--) {
-                const int ipivot = D.prow[k], jpivot = D.pcol[k];
-                const double w = W.work[ipivot];
-                if (w != 0.0) {
-                    const double x = w / GU.pivot(ipivot);
-                    wave_mem_sync();
-                    if (lane == 0) W.work[ipivot] = 0.0;
-                    const int b = GU.begin(ipivot), e = GU.end(ipivot);
-                    for (int p = b + lane; p < e; p += 64) {
-                        const int i = GU.node(p);
-                        W.work[i] = __dsub_rn(W.work[i], __dmul_rn(x, GU.val(p)));
-                    }
-                    u_flops += e - b;
-                    if (fabs(x) > droptol) {
-                        if (lane == 0) {
-                            W.ilhs[nz] = jpivot;
-                            W.xlhs[jpivot] = x;
-                        }
-                        nz++;
-                    }
-                    wave_mem_sync();
+            sweep_nonzeros_desc(m, W.work, [&](int k) { return D.prow[k]; }, [&](int k, int ipivot, double w) {
+                const int jpivot = D.pcol[k];
+                const double x = w / GU.pivot(ipivot);
+                if (lane == 0) W.work[ipivot] = 0.0;
+                const int b = GU.begin(ipivot), e = GU.end(ipivot);
+                for (int p = b + lane; p < e; p += 64) {
+                    const int i = GU.node(p);
+                    W.work[i] = __dsub_rn(W.work[i], __dmul_rn(x, GU.val(p)));
                 }
-            }
+                u_flops += e - b;
+                if (fabs(x) > droptol) {
+                    if (lane == 0) {
+                        W.ilhs[nz] = jpivot;
+                        W.xlhs[jpivot] = x;
+                    }
+                    nz++;
+                }
+            });
         }
     }
     // hand the solution out in compressed form and restore the all-zero invariant of xlhs

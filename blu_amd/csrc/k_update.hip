@@ -316,26 +316,21 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             } else {
                 branch = 2;
                 nz = 0;
-                for (int k = m - 1; k >= 0; k--) {
-                    const int ipivot = D.prow[k];
-                    const double x = W.xlhs[ipivot];
-                    if (x != 0.0) {
-                        const int b = GT.begin(ipivot), e = GT.end(ipivot);
-                        for (int p = b + lane; p < e; p += 64) {
-                            const int i = GT.node(p);
-                            W.xlhs[i] = __dsub_rn(W.xlhs[i], __dmul_rn(x, GT.val(p)));
-                        }
-                        l_flops += e - b;
-                        wave_mem_sync();
-                        if (fabs(x) > droptol) {
-                            if (lane == 0) W.ilhs[nz] = ipivot;
-                            nz++;
-                        } else if (lane == 0) {
-                            W.xlhs[ipivot] = 0.0;
-                        }
-                        wave_mem_sync();
+                sweep_nonzeros_desc(m, W.xlhs, [&](int k) { return D.prow[k]; }, [&](int, int ipivot, double x) {
+                    const int b = GT.begin(ipivot), e = GT.end(ipivot);
+                    for (int p = b + lane; p < e; p += 64) {
+                        const int i = GT.node(p);
+                        W.xlhs[i] = __dsub_rn(W.xlhs[i], __dmul_rn(x, GT.val(p)));
                     }
-                }
+                    l_flops += e - b;
+                    wave_mem_sync();
+                    if (fabs(x) > droptol) {
+                        if (lane == 0) W.ilhs[nz] = ipivot;
+                        nz++;
+                    } else if (lane == 0) {
+                        W.xlhs[ipivot] = 0.0;
+                    }
+                });
             }
         }
     } else {
@@ -426,29 +421,25 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             } else { // sequential solve over the pivot sequence (duplicates allowed: a row already done holds zero)
                 branch = 2;
                 nz = 0;
-                for (int k = st->pivotlen - 1; k >= 0; k--) {
-                    const int ipivot = U.pvrow[k], jpivot = U.pvcol[k];
-                    const double w = W.work[ipivot];
-                    if (w != 0.0) {
-                        const double x = w / U.row_pivot[ipivot];
-                        wave_mem_sync();
-                        if (lane == 0) W.work[ipivot] = 0.0;
-                        const int b = GU.begin(ipivot), e = GU.end(ipivot);
-                        for (int p = b + lane; p < e; p += 64) {
-                            const int i = GU.node(p);
-                            W.work[i] = __dsub_rn(W.work[i], __dmul_rn(x, GU.val(p)));
-                        }
-                        u_flops += e - b;
-                        if (fabs(x) > droptol) {
-                            if (lane == 0) {
-                                W.ilhs[nz] = jpivot;
-                                W.xlhs[jpivot] = x;
-                            }
-                            nz++;
-                        }
-                        wave_mem_sync();
+                // (a row that occurs twice in the sequence holds zero when its earlier position is reached)
+                sweep_nonzeros_desc(st->pivotlen, W.work, [&](int k) { return U.pvrow[k]; }, [&](int k, int ipivot, double w) {
+                    const int jpivot = U.pvcol[k];
+                    const double x = w / U.row_pivot[ipivot];
+                    if (lane == 0) W.work[ipivot] = 0.0;
+                    const int b = GU.begin(ipivot), e = GU.end(ipivot);
+                    for (int p = b + lane; p < e; p += 64) {
+                        const int i = GU.node(p);
+                        W.work[i] = __dsub_rn(W.work[i], __dmul_rn(x, GU.val(p)));
                     }
-                }
+                    u_flops += e - b;
+                    if (fabs(x) > droptol) {
+                        if (lane == 0) {
+                            W.ilhs[nz] = jpivot;
+                            W.xlhs[jpivot] = x;
+                        }
+                        nz++;
+                    }
+                });
             }
         }
     }
