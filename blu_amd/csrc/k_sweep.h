@@ -188,6 +188,10 @@ __device__ __forceinline__ void sweep(const Cols &C, int k0, int dir, int n, Bod
 
 // ------------------------------------------------------------------------------------------------
 // The same sweeps with the memory round trip taken OFF the step-to-step dependency.
+// (Round 2 tried the look-ahead three steps deep -- gathers and own values fetched three steps ahead, the terms of
+// the steps in between kept as products and applied in step order: bit-identical, and SLOWER, k_stats 177 -> 197 ms
+// at C3.  A step is not waiting for memory any more: it is ~200 dependent instructions of one wave -- ordered sum,
+// f64 division, 64-bit address arithmetic of five prefetches -- at ~7 cycles each.)
 //
 // sweep_dot: step k forms  s_k = ordered dot(column k, x),  v_k = f(k, P_k, s_k, own_k)  and stores
 // x[w_k] = v_k.  The gather x[idx] of step k+1 is issued BEFORE step k is worked (entries two steps
