@@ -17,7 +17,18 @@
 #include "../../include/blu_hip.h"
 #include "blu_dev.h"
 #include "k_finish.hip"
+#define BLU_NS pv_single
+#define BLU_CFG_BATCH 0
 #include "k_pivot.hip"
+#undef BLU_NS
+#undef BLU_CFG_BATCH
+#define BLU_NS pv_batch
+#define BLU_CFG_BATCH 1
+#include "k_pivot.hip"
+#undef BLU_NS
+#undef BLU_CFG_BATCH
+using pv_single::k_pivot_loop;
+using pv_batch::k_pivot_loop_batch;
 #include "k_prep.hip"
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"

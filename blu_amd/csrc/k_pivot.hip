@@ -18,6 +18,13 @@
 //   * arithmetic: a = xrj / pivot; w -= a * c with separate roundings (no FMA)
 #include "blu_dev.h"
 
+// This file is compiled TWICE into one translation unit (blu_hip.hip), each time inside its own namespace:
+//   pv_single   k_pivot_loop        one matrix, one 1024-thread workgroup, the full-size LDS working set
+//   pv_batch    k_pivot_loop_batch  many matrices, small workgroups, BLU_CFG_BATCH: a working set sized for the
+//                                    shapes that make up practically all pivots, so that many workgroups share a CU
+// (shapes beyond the small working set take the general paths, as in the other configuration).
+namespace BLU_NS {
+
 // A failed check also raises this LDS flag, so the pivot loop can stop at the next pivot boundary
 // without polling the status word in HBM every iteration.
 __shared__ int g_pivot_err;
@@ -31,7 +38,7 @@ __shared__ int g_pivot_err_line; // source line of a bounded loop that overran (
         }                                                \
     } while (0)
 
-#include "k_pivot_fast_types.h"
+#include "k_pivot_fast_types.h" // (re-included per configuration: no include guard)
 
 // Diagnostic build (-DBLU_PROFILE, `make prof`): thread 0 stamps the shader clock at phase boundaries
 // of the pivot loop.  The product build contains no stamps.
@@ -1430,6 +1437,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
     }
 }
 
+#if !BLU_CFG_BATCH
 // One matrix: all 16 waves of a CU, 128 VGPRs.
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {
@@ -1437,15 +1445,32 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
     __shared__ Mc mcache;
     pivot_loop_body<false>(Ds, stop_at, &smem, &mcache);
 }
-// Many matrices (batch): workgroups of <= 256 threads = 4 waves, so only 4 of the 16 work columns at the
-// end of Sm are allocated, and a register budget for BLU_BATCH_WAVES waves per SIMD: that many
-// workgroups share a CU (LDS is handed out in 1280-byte granules: 160 KB / 6 -> 25 600 bytes each).
+#else
+// Many matrices (batch): workgroups of <= BLU_BATCH_THREADS threads, so only that many of the 16 per-wave work
+// columns at the end of Sm are allocated, and a register budget for BLU_BATCH_WAVES waves per SIMD.  LDS is handed
+// out in 1280-byte granules.
 #ifndef BLU_BATCH_WAVES
 #define BLU_BATCH_WAVES 6
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BLU_BATCH_WAVES, BLU_BATCH_WAVES)))
+#ifndef BLU_BATCH_THREADS
+#define BLU_BATCH_THREADS 256
+#endif
+__global__ void __launch_bounds__(BLU_BATCH_THREADS) __attribute__((amdgpu_waves_per_eu(BLU_BATCH_WAVES, BLU_BATCH_WAVES)))
 k_pivot_loop_batch(DevLU *Ds, int stop_at)
 {
-    __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - 12 * 64 * sizeof(double)];
+    __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - (16 - BLU_BATCH_THREADS / 64) * 64 * sizeof(double)];
     pivot_loop_body<true>(Ds, stop_at, reinterpret_cast<Sm *>(raw), nullptr);
 }
+#endif
+
+} // namespace BLU_NS
+#undef PROF_STAMP
+#undef PROF_STAMP_L0
+#undef PROF_WAIT
+#undef COLD
+// the other kernels of the translation unit use the plain check of blu_dev.h (no LDS flag)
+#undef DEV_CHECK
+#define DEV_CHECK(S, cond)                                   \
+    do {                                                     \
+        if (!(cond)) set_error((S), ST_ERROR, __LINE__);     \
+    } while (0)

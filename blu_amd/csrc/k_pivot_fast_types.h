@@ -1,14 +1,37 @@
 // k_pivot_fast_types.h -- LDS working set of the low-latency pivot paths (see k_pivot_fast.hip)
-#pragma once
+// (no include guard: k_pivot.hip includes this once per configuration, inside its namespace)
+#undef PCMAX
+#undef PRMAX
+#undef STGMAX
+#undef KCMAX
+#undef HROW
+#undef HCOL
+#undef KGMAX
+#undef HROW_BITS
+#undef HCOL_BITS
+#undef MC_HEADS
+#undef MC_PREV
 #define PCMAX 65    // cached pivot column entries (pivot_small: <= 64 off-diagonals)
+#define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
+#if BLU_CFG_BATCH
+// batch configuration: pivot rows up to 64 entries (all of them on the banded LP bases; longer rows take the
+// general paths), hash tables at half load for that, ~11 KB of LDS per workgroup instead of ~24 KB
+#define PRMAX 64
+#define STGMAX 80
+#define HROW 128
+#define HCOL 128
+#define KGMAX 64
+#define HROW_BITS 7
+#define HCOL_BITS 7
+#else
 #define PRMAX 256   // cached pivot row entries
 #define STGMAX 104  // staged Markowitz candidate entries
-#define KCMAX 4     // candidate columns handled by the flattened search (maxsearch <= KCMAX)
 #define HROW 256    // hash slots, rows of the pivot column (<= 64 keys)
 #define HCOL 512    // hash slots, columns of the pivot row (<= 256 keys)
-#define KGMAX 128    // batched list moves: keys (new counts) below this meet in an LDS table
+#define KGMAX 128   // batched list moves: keys (new counts) below this meet in an LDS table
 #define HROW_BITS 8
 #define HCOL_BITS 9
+#endif
 // Early search (early_search in k_pivot_fast.hip): when the next pivot is a column singleton, wave 0 finds
 // and stages it while the other waves write out the current pivot.  -DBLU_EARLY=0 switches it off; `make
 // ewcheck` builds a library that verifies every early result against the ordinary search.
