@@ -395,6 +395,8 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_NSYMPERM_TOTAL: return (double)h->ust.nsymperm_total;
     case BLU_STAT_NFORREST_TOTAL: return (double)h->ust.nforrest_total;
     case BLU_STAT_DEV_NUNSYMPERM_TOTAL: return (double)h->ust.nunsymperm_total;
+    case BLU_STAT_UPDATE_COST: // lu.rs:324-326; the numerator is reset by factorize (lu.rs:346)
+        return (h->upd_for_nfact == h->nfactorize ? h->ust.update_cost_numer : 0.0) / blu_hip_get_stat(h, BLU_STAT_UPDATE_COST_DENOM);
     case 44: case 45: case 46: case 47: return h->t_phase[key - 44]; // device seconds of k_prep / k_setup / k_finish / k_stats
     case 43: return (double)h->sp_branch; // branch of the last solve_sparse: 1 sparse, 2 sequential
     case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;

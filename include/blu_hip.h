@@ -96,7 +96,8 @@ enum blu_stat {
     BLU_STAT_DEV_RELAUNCHES = 42,       /* pivot-loop kernel launches of last factorize */
     BLU_STAT_NSYMPERM_TOTAL = 48,       /* lu.nsymperm_total: updates done by a symmetric permutation alone */
     BLU_STAT_NFORREST_TOTAL = 49,       /* lu.nforrest_total */
-    BLU_STAT_DEV_NUNSYMPERM_TOTAL = 59  /* updates done by an unsymmetric permutation (update.rs:794-814); no getter in the reference */
+    BLU_STAT_DEV_NUNSYMPERM_TOTAL = 59, /* updates done by an unsymmetric permutation (update.rs:794-814); no getter in the reference */
+    BLU_STAT_UPDATE_COST = 124          /* LU::update_cost() = update_cost_numer / update_cost_denom (lu.rs:324-326) */
 };
 
 typedef struct blu_hip blu_hip; /* opaque: owns all device + host state (= struct LU + struct BLU) */

@@ -421,6 +421,7 @@ double orc_get_stat(const orc_lu *lu, int key)
     case BLU_STAT_NSYMPERM_TOTAL: return (double)lu->nsymperm_total;
     case BLU_STAT_NFORREST_TOTAL: return (double)lu->nforrest_total;
     case BLU_STAT_DEV_NUNSYMPERM_TOTAL: return (double)lu->nunsymperm_total;
+    case BLU_STAT_UPDATE_COST: return lu->update_cost_numer / lu->update_cost_denom; /* lu.rs:324-326 */
     case 50: return (double)lu->d3_hits;
     case 51: case 52: case 53: case 54: case 55: case 56: return (double)lu->npivot_kind[key - 51];
     default: return NAN;
