@@ -1121,6 +1121,12 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, 
     }
 }
 
+// (Round 2 built "two lines per wave": pair forms of fast_col / fast_row running one instruction stream on two
+// lines, lanes 0-31 and 32-63, ballots split into halves, half-wide broadcasts by two v_readlane and a select,
+// rows of up to 64 entries in two register chunks -- 18 pair tasks per small pivot instead of 35 line tasks.
+// Bit-identical (87 parity tests), and no faster: a pair costs 5 500 cycles against 3 500 for one line (the
+// half-wide selects, twice the LDS set-up per task, more spilled registers) and the task set-up doubles, so a
+// wave's share takes as long as before: C3 pivot loop 820 -> 842 ms, batch kernel 1.21 -> 1.18 s.  Not kept.)
 // rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
 __device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, Mc *mc, int p)
 {
