@@ -284,7 +284,9 @@ def rank_main(args, backend=None, device=None):
         traffic = tinfo["hbm_bytes_per_launch"] / max(t_kernel, 1e-12) / 1e9
     achieved = bytes_elim * args.steps / max(t_pivot, 1e-12) / 1e9
     phases = {}
-    for name, key in (("k_prep", 44), ("k_setup", 45), ("k_finish", 46), ("k_stats", 47)):
+    # k_stats = the whole statistics tail (single matrix: k_rows_grid + k_stats_chains + k_stats_tail, of which the
+    # first and the last are also listed on their own)
+    for name, key in (("k_prep", 44), ("k_setup", 45), ("k_finish", 46), ("k_stats", 47), ("k_rows_grid", 108), ("k_stats_tail", 109)):
         val = h.stat(key)
         if val == val and val > 0:
             phases[name + "_ms"] = 1e3 * val

@@ -33,6 +33,7 @@ using pv_batch::k_pivot_loop_batch;
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"
 #include "k_stats.hip"
+#include "k_chain.hip"
 #include "k_update.hip"
 
 #define BLU_STOPPED_STATUS 100 /* debug stepping only */
@@ -84,7 +85,13 @@ struct blu_hip {
     hipStream_t stream;
     hipEvent_t ev[4];
     double t_total, t_pivot;
-    double t_phase[4]; // k_prep, k_setup, k_finish, k_stats of the last factorize (seconds, HIP events)
+    double t_phase[6]; // k_prep, k_setup, k_finish, statistics (all of it), and inside the statistics: k_rows_grid, k_stats_tail (seconds, HIP events)
+    // single-matrix statistics / solve_dense on the chain pipeline (k_chain.hip)
+    int chain_ok;           // 1: the device grants the LDS the chain kernels need
+    int *ur_len, *ur_pos;   // U rows sorted descending in pivot order (k_rows_grid)
+    double *ur_val;
+    int64_t ur_cap;
+    int64_t rows_for_nfact; // nfactorize the sorted U rows were built for (-1: none)
     int relaunches;
     int block_threads; // workgroup size of the pivot kernel
     int no_fast;       // debug: disable the LDS fast paths
@@ -146,6 +153,7 @@ static void free_all(blu_hip *h)
     dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
     dfree(W.xval); dfree(W.out); dfree(W.lt_ptr); dfree(W.lt_idx); dfree(W.lt_val); dfree(W.lt_cur);
     dfree(h->d_irhs); dfree(h->d_xrhs);
+    dfree(h->ur_len); dfree(h->ur_pos); dfree(h->ur_val);
     free_upd(h);
     // everything else lives in the slab
     dfree(h->slab);
@@ -225,6 +233,11 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->upd_alloc_m = -1;
     h->upd_for_nfact = -1;
     h->upd_extra = -1;
+    h->chain_ok = 0;
+    h->ur_len = h->ur_pos = nullptr;
+    h->ur_val = nullptr;
+    h->ur_cap = 0;
+    h->rows_for_nfact = -1;
     h->stop_at = -1;
     h->block_threads = 1024;
     h->no_fast = 0;
@@ -277,13 +290,19 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->batch_block = 256;
     if (ok) { // chip-wide phases: as many workgroups as are certainly co-resident, at most 64 (one per CU of two XCDs' worth)
         int nb = 0, best = 1 << 30;
-        const void *fns[3] = {(const void *)k_prep_grid, (const void *)k_setup_grid, (const void *)k_finish_grid};
-        for (int k = 0; k < 3; k++) {
+        const void *fns[4] = {(const void *)k_prep_grid, (const void *)k_setup_grid, (const void *)k_finish_grid, (const void *)k_rows_grid};
+        for (int k = 0; k < 4; k++) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], 1024, 0) != hipSuccess) nb = 0;
             best = std::min(best, nb * prop.multiProcessorCount);
         }
         h->grid_blocks = std::max(1, std::min(best, 64));
         if (!prop.cooperativeLaunch) h->grid_blocks = 1;
+        // the chain kernels keep ~106 KB of LDS rings per workgroup (k_chain.h)
+        h->chain_ok = h->grid_blocks > 1 && (size_t)prop.sharedMemPerBlock >= sizeof(ChainLds) &&
+                      hipFuncSetAttribute((const void *)k_stats_chains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainLds)) == hipSuccess &&
+                      hipFuncSetAttribute((const void *)k_solve_dense_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainLds)) == hipSuccess;
+        if (!h->chain_ok) (void)hipGetLastError();
+        if (getenv("BLU_HIP_NO_CHAIN")) h->chain_ok = 0; // diagnostic: the one-workgroup kernels of a batch
     }
     if (ok) ok = hip_ok(h, hipStreamCreate(&h->stream), "hipStreamCreate");
     for (int k = 0; ok && k < 4; k++) ok = hip_ok(h, hipEventCreate(&h->ev[k]), "hipEventCreate");
@@ -398,6 +417,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_UPDATE_COST: // lu.rs:324-326; the numerator is reset by factorize (lu.rs:346)
         return (h->upd_for_nfact == h->nfactorize ? h->ust.update_cost_numer : 0.0) / blu_hip_get_stat(h, BLU_STAT_UPDATE_COST_DENOM);
     case 44: case 45: case 46: case 47: return h->t_phase[key - 44]; // device seconds of k_prep / k_setup / k_finish / k_stats
+    case 108: case 109: return h->t_phase[key - 108 + 4]; // inside the statistics: k_rows_grid, k_stats_tail
     case 43: return (double)h->sp_branch; // branch of the last solve_sparse: 1 sparse, 2 sequential
     case BLU_STAT_DEV_TIME_PIVOT_LOOP: return h->t_pivot;
     case BLU_STAT_DEV_TIME_TOTAL: return h->t_total;
@@ -508,6 +528,9 @@ static bool ensure_out(blu_hip *h, int64_t ln, int64_t un)
     return true;
 }
 
+static int ensure_rows_ws(blu_hip *h, int64_t lnz, int64_t unz);
+static RowsWs rows_ws_of(blu_hip *h);
+static bool launch_rows(blu_hip *h, DevLU *dD, hipStream_t stream);
 #include "blu_driver.inc"
 
 // BLU::get_factors -- src/blu.rs:139, get_factors.rs:48-180
@@ -578,6 +601,57 @@ static int ensure_lt(blu_hip *h)
     return BLU_OK;
 }
 
+// Row-wise copies for the chain pipeline (single-matrix path): row-wise L into the buffers ensure_lt owns, U rows
+// sorted descending; k_rows_grid on `stream`.  `nfact` = the nfactorize value these factors will carry.
+static int ensure_rows_ws(blu_hip *h, int64_t lnz, int64_t unz)
+{
+    const int st = ensure_sparse_ws(h);
+    if (st != BLU_OK) return st;
+    SparseWs &W = h->sw;
+    lnz = std::max<int64_t>(lnz, 1);
+    unz = std::max<int64_t>(unz, 1);
+    if (lnz > h->sw_ltcap) {
+        dfree(W.lt_idx);
+        dfree(W.lt_val);
+        if (!dalloc(h, &W.lt_idx, (size_t)lnz) || !dalloc(h, &W.lt_val, (size_t)lnz)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->sw_ltcap = lnz;
+        h->lt_for_nfact = -1;
+    }
+    if (!h->ur_len && !dalloc(h, &h->ur_len, (size_t)h->m)) return BLU_ERROR_OUT_OF_MEMORY;
+    if (unz > h->ur_cap) {
+        dfree(h->ur_pos);
+        dfree(h->ur_val);
+        if (!dalloc(h, &h->ur_pos, (size_t)unz) || !dalloc(h, &h->ur_val, (size_t)unz)) return BLU_ERROR_OUT_OF_MEMORY;
+        h->ur_cap = unz;
+        h->rows_for_nfact = -1;
+    }
+    return BLU_OK;
+}
+static RowsWs rows_ws_of(blu_hip *h)
+{
+    RowsWs R;
+    R.lt_ptr = h->sw.lt_ptr;
+    R.lt_idx = h->sw.lt_idx;
+    R.lt_val = h->sw.lt_val;
+    R.lt_cur = h->sw.lt_cur;
+    R.ur_len = h->ur_len;
+    R.ur_pos = h->ur_pos;
+    R.ur_val = h->ur_val;
+    return R;
+}
+static bool launch_rows(blu_hip *h, DevLU *dD, hipStream_t stream)
+{
+    if (hipMemsetAsync(h->gw, 0, sizeof(GridWs), stream) != hipSuccess) return false;
+    RowsWs R = rows_ws_of(h);
+    void *a0 = (void *)dD, *a1 = (void *)h->gw;
+    void *args[3] = {&a0, &a1, &R};
+    if (hipLaunchCooperativeKernel((const void *)k_rows_grid, dim3(h->grid_blocks), dim3(1024), args, 0, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
 #include "blu_update.inc"
 
 // BLU::solve_dense -- src/blu.rs:182, lu/solve_dense.rs:7-120
@@ -594,6 +668,14 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     if (h->nupdate > 0) { // updated factorization: mutable U, row etas, pivot sequence (k_update.hip)
         const int st = solve_dense_updated(h, tr);
         if (st != BLU_OK) return st;
+        if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
+        return BLU_OK;
+    }
+    // a factorization whose row-wise copies exist (a single factorize on a device with the LDS for it): the chain pipeline
+    if (h->chain_ok && h->rows_for_nfact == h->nfactorize && h->lt_for_nfact == h->nfactorize) {
+        hipLaunchKernelGGL(k_solve_dense_chain, dim3(1), dim3(CHAIN_THREADS), sizeof(ChainLds), h->stream, h->dD, h->dO, rows_ws_of(h), h->d_rhs,
+                           h->d_lhs, tr);
+        if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_dense_chain")) return BLU_ERROR_DEVICE;
         if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
         return BLU_OK;
     }

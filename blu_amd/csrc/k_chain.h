@@ -1,0 +1,377 @@
+// k_chain.h -- triangular sweeps as a decoupled access / execute pipeline, one workgroup per sweep chain.
+//
+// A triangular sweep (condest.rs, residual_test.rs, solve_dense.rs) is a chain of m dependent steps.  On the
+// banded LP bases the chain is real: the U of the C3 basis has a dependency path of 50 380 steps (SURVEY 8d's
+// tri_frac = 0.5 part is one long chain; L has depth 571), so level scheduling has nothing to offer there and
+// what counts is the time of ONE step.  k_sweep.h runs a sweep on one wave that also fetches its own operands
+// from global memory one and two steps ahead: a step then takes a global round trip (~0.85 us), because the
+// wave has to wait for the loads of this step before it can start the next.
+//
+// Here the wave that walks the chain never loads from global memory.  The other waves of the workgroup
+// (helpers) stream the operands of the coming steps into LDS rings -- step records (length, pivot, own value,
+// output index) and entries (value, and WHERE the operand of the work vector is found) -- hundreds of steps
+// ahead of the chain wave; the chain wave reads LDS only, three steps deep in registers, and its step is the
+// arithmetic: products, the ordered sum in the reference's order, the step function (one f64 division), one
+// LDS and one global store.  Work-vector operands come from
+//   * a window of the last CH_W results in LDS (xwin, written by the chain wave itself),
+//   * the previous step's result, forwarded in a register,
+//   * for producers further back than the window: the value gathered from global memory by the helper
+//     (final for at least CH_W - CH_CS steps when the helper reads it; the chain wave drains its stores
+//     before it publishes the progress the helper waits for).
+// Every sweep is in GATHER form: step k reads results of earlier steps only.  The reference's scatter-form
+// loops (x[i] -= t_k * a_ik over column k, k in sweep order) are run over the transposed storage -- row-wise L
+// ascending, U rows descending in the pivot order (k_rows_grid below) -- accumulating into the step's own
+// entry in the same order with the same two roundings per term, so all results stay bit-identical.
+//
+// Flow control (LDS, in-order per wave): helpers take blocks of CH_SB steps round-robin; the entry-ring base of a
+// block is handed from the helper of the previous block as soon as that one knows its entry count; a block is
+// staged only when its step-ring slots (chain CH_NB blocks behind) and its entry-ring space are free; the chain
+// wave waits for blk_ready of the block it enters.  Steps with more than 64 entries are not staged: the chain
+// wave takes them straight from global memory (its own stores are ordered before its later loads).
+#pragma once
+#include "blu_dev.h"
+
+#define CH_SB 32                 // steps per block
+#define CH_NB 8                  // blocks in the step ring
+#define CH_CS (CH_SB * CH_NB)    // step ring
+#define CH_CE 4096               // entry ring (two full blocks of 64-entry steps)
+#define CH_W 2048                // window of results kept in LDS (positions)
+#define CH_HT 16                 // hand-off ring of entry bases
+#define CH_SEL_FAR (-1)          // operand: the helper's gathered value
+#define CH_SEL_PREV (-2)         // operand: the previous step's result (register)
+
+struct __attribute__((aligned(16))) ChRecA { // what the chain wave reads of a step, in two 16-byte LDS reads
+    int n, eb, w, k;
+};
+struct __attribute__((aligned(16))) ChRecB {
+    double diag, own;
+};
+struct __attribute__((aligned(16))) ChOpsV {
+    double val, xv;
+};
+struct ChainLds {
+    ChOpsV ev[CH_CE];
+    int sel[CH_CE];
+    double xwin[CH_W];
+    ChRecA ra[CH_CS];
+    ChRecB rb[CH_CS];
+    long long s_b[CH_CS];
+    volatile int blk_ready[CH_NB];
+    volatile int eb_tag[CH_HT];
+    volatile int eb_val[CH_HT];
+    volatile int chain_done; // blocks finished by the chain wave with their stores drained
+    volatile int chain_eb;   // entry-ring position of the first entry not consumed by those blocks
+    volatile int abort;      // a wait ran into its bound (a defect, never a valid state): everybody leaves
+};
+
+struct ChMeta {
+    long long b; // storage offset of the step's entries
+    int len;     // number of entries
+    int w;       // index of the output vector the step writes
+    double diag, own;
+};
+struct ChEnt {
+    int pos;  // sweep position k of the producer (0..m-1)
+    int gidx; // its index in the output vector
+    double val;
+};
+
+// Bounded wait on LDS state written by another wave: ~2^22 polls (seconds) and the sweep is abandoned with an
+// error instead of hanging the GPU.
+#define CH_WAIT(L, cond, code)                                         \
+    do {                                                            \
+        int it_ = 0;                                                \
+        while (!(cond)) {                                           \
+            if ((L)->abort || ++it_ > (1 << 19)) {                  \
+                if (!(L)->abort) (L)->abort = (code);               \
+                break;                                              \
+            }                                                       \
+            __builtin_amdgcn_s_sleep(1);                            \
+        }                                                           \
+    } while (0)
+
+__device__ __forceinline__ void ch_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void ch_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ double ch_load_final(gdouble_p p)
+{
+    // a value another wave of this workgroup stored some time ago: read past this CU's vector cache
+    const long long b = __hip_atomic_load((GPTR(const long long))p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double(b);
+}
+
+// ---- helper side: stage block b ---------------------------------------------------------------------------
+template <class A>
+__device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, int k0, int dir, int nsteps, gdouble_p out)
+{
+    const int lane = lane_id();
+    const int s0 = b * CH_SB;
+    const int ns = nsteps - s0 < CH_SB ? nsteps - s0 : CH_SB;
+    const int k = k0 + dir * (s0 + (lane < ns ? lane : 0));
+    ChMeta M = ad.meta(k);
+    if (M.len < 0) M.len = 0; // (defensive: a negative length would make the loops below unbounded)
+    const bool mine = lane < ns;
+    const int st = (mine && M.len <= 64) ? M.len : 0;
+    const int incl = wave_incl_scan_i(st);
+    const int off = incl - st;
+    const int cnt = __builtin_amdgcn_readlane(incl, 63);
+    // entry-ring base: from the helper of the previous block
+    int base = 0;
+    if (b > 0) {
+        CH_WAIT(L, L->eb_tag[b & (CH_HT - 1)] == b, 1);
+        base = L->eb_val[b & (CH_HT - 1)];
+    }
+    if (lane == 0) {
+        L->eb_val[(b + 1) & (CH_HT - 1)] = base + cnt;
+        ch_lds_fence();
+        L->eb_tag[(b + 1) & (CH_HT - 1)] = b + 1;
+    }
+    // room: step-ring slots of block b - CH_NB, entry-ring space; this also makes every result further back
+    // than the window final and visible (see the header)
+    CH_WAIT(L, L->chain_done >= b - CH_NB + 1 && base + cnt - L->chain_eb <= CH_CE, 2);
+    asm volatile("" ::: "memory");
+    if (L->abort) return;
+    const int slot0 = s0 & (CH_CS - 1);
+    if (mine) {
+        const int sl = slot0 + lane;
+        ChRecA a;
+        a.n = M.len <= 64 ? M.len : -1;
+        a.eb = base + off;
+        a.w = M.w;
+        a.k = k;
+        L->ra[sl] = a;
+        ChRecB bq;
+        bq.diag = M.diag;
+        bq.own = M.own;
+        L->rb[sl] = bq;
+        L->s_b[sl] = M.b;
+    }
+    ch_lds_fence();
+    // entries, flat over the block: 4 x 64 per pass, loads of a pass issued together
+    for (int f0 = 0; f0 < cnt; f0 += 256) {
+        int tt[4], ee[4];
+        ChEnt E[4];
+        bool ok[4], far[4];
+        double xo[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = f0 + u * 64 + lane;
+            ok[u] = f < cnt;
+            // step of flat entry f: the last t with s_eb[t] - base <= f (binary search over the block's records)
+            int lo = 0, hi = ns - 1;
+            const int target = base + (ok[u] ? f : 0);
+#pragma unroll
+            for (int it = 0; it < 5; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                const bool ge = (L->ra[slot0 + mid].eb <= target) && (mid <= hi);
+                lo = ge ? mid : lo;
+                hi = ge ? hi : mid - 1;
+            }
+            // skip unstaged / empty steps that share the same base: take the LAST step with s_eb <= target that has entries
+            tt[u] = lo;
+            ee[u] = target - L->ra[slot0 + lo].eb;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            E[u].pos = 0;
+            E[u].gidx = 0;
+            E[u].val = 0.0;
+            if (ok[u]) E[u] = ad.ent(L->ra[slot0 + tt[u]].k, L->s_b[slot0 + tt[u]], ee[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = L->ra[slot0 + tt[u]].k;
+            const int d = (kk - E[u].pos) * dir;
+            far[u] = ok[u] && d >= CH_W;
+            xo[u] = 0.0;
+            if (far[u]) xo[u] = ch_load_final(out + E[u].gidx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (ok[u]) {
+                const int kk = L->ra[slot0 + tt[u]].k;
+                const int r = (base + f0 + u * 64 + lane) & (CH_CE - 1);
+                ChOpsV ov;
+                ov.val = E[u].val;
+                ov.xv = xo[u];
+                L->ev[r] = ov;
+                L->sel[r] = far[u] ? CH_SEL_FAR : (E[u].pos == kk - dir ? CH_SEL_PREV : (E[u].pos & (CH_W - 1)));
+            }
+        }
+    }
+    ch_lds_fence();
+    if (lane == 0) L->blk_ready[b & (CH_NB - 1)] = b + 1;
+}
+
+// ---- chain side -------------------------------------------------------------------------------------------
+struct ChRec {
+    int n, eb, w, k;
+    double diag, own;
+};
+struct ChOps {
+    double val, xv;
+    int sel;
+};
+__device__ __forceinline__ ChRec ch_read_rec(ChainLds *L, int s)
+{
+    const int sl = s & (CH_CS - 1);
+    const ChRecA a = L->ra[sl];
+    const ChRecB b = L->rb[sl];
+    ChRec R;
+    R.n = __builtin_amdgcn_readfirstlane(a.n);
+    R.eb = __builtin_amdgcn_readfirstlane(a.eb);
+    R.w = __builtin_amdgcn_readfirstlane(a.w);
+    R.k = __builtin_amdgcn_readfirstlane(a.k);
+    R.diag = b.diag;
+    R.own = b.own;
+    return R;
+}
+__device__ __forceinline__ ChOps ch_read_ops(ChainLds *L, const ChRec &R)
+{
+    ChOps E;
+    E.val = 0.0;
+    E.xv = 0.0;
+    E.sel = CH_SEL_FAR;
+    if (lane_id() < R.n) {
+        const int r = (R.eb + lane_id()) & (CH_CE - 1);
+        const ChOpsV v = L->ev[r];
+        E.val = v.val;
+        E.xv = v.xv;
+        E.sel = L->sel[r];
+    }
+    return E;
+}
+// acc -/+= the products of lanes 0..n-1, in lane order (the reference's sequential loop)
+template <bool SUB>
+__device__ __forceinline__ double ch_accumulate(double acc, double prod, int n)
+{
+    const unsigned lo = (unsigned)__double_as_longlong(prod), hi = (unsigned)(__double_as_longlong(prod) >> 32);
+#define CH_TERM(T)                                                                                              \
+    {                                                                                                           \
+        const unsigned a_ = __builtin_amdgcn_readlane(lo, (T)), b_ = __builtin_amdgcn_readlane(hi, (T));        \
+        const double term_ = __longlong_as_double((long long)(((unsigned long long)b_ << 32) | a_));            \
+        acc = SUB ? __dsub_rn(acc, term_) : __dadd_rn(acc, term_);                                              \
+    }
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {
+        CH_TERM(t)
+        CH_TERM(t + 1)
+        CH_TERM(t + 2)
+        CH_TERM(t + 3)
+    }
+    for (; t < n; t++) CH_TERM(t)
+#undef CH_TERM
+    return acc;
+}
+
+// One sweep by the whole workgroup: wave 0 walks the chain, the other waves stage.  All waves must call it.
+//   INIT_OWN: the accumulator starts at the step's own value (scatter-form loops of the reference), else at 0
+//   SUB:      terms are subtracted, else added
+//   f(k, has_entries, acc, own, diag) -> the step's result, stored to out[w] and the window; f may store more
+// On return every store of the sweep has completed and the workgroup is synchronised; false: abandoned (defect).
+template <bool INIT_OWN, bool SUB, class A, class F>
+__device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, int dir, int nsteps, gdouble_p out, F f)
+{
+    const int w = wave_id(), nw = num_waves(), lane = lane_id();
+    const int nblk = (nsteps + CH_SB - 1) / CH_SB;
+    if (threadIdx.x < CH_NB) L->blk_ready[threadIdx.x] = 0;
+    if (threadIdx.x < CH_HT) L->eb_tag[threadIdx.x] = -1;
+    if (threadIdx.x == 0) {
+        L->chain_done = 0;
+        L->chain_eb = 0;
+        L->abort = 0;
+    }
+    __syncthreads();
+    if (w > 0) {
+        for (int b = w - 1; b < nblk && !L->abort; b += nw - 1) ch_stage_block(ad, L, b, k0, dir, nsteps, out);
+    } else if (nsteps > 0) {
+#ifdef BLU_PROFILE
+        long long t_wait = 0, t_drain = 0;
+        const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        // The records of the steps past the end read as empty: the ring slots behind the last block are written
+        // as "n = 0" by nobody, so the look-ahead below is clamped to the last step instead.
+        const auto wait_block = [&](int b) {
+            if (b < nblk) {
+                CH_WAIT(L, L->blk_ready[b & (CH_NB - 1)] == b + 1, 3);
+                asm volatile("" ::: "memory");
+            }
+        };
+        const int last = nsteps - 1;
+        wait_block(0);
+        wait_block(1);
+        ChRec R1 = ch_read_rec(L, 0);
+        ChOps E1 = ch_read_ops(L, R1);
+        double xw1 = E1.sel >= 0 ? L->xwin[E1.sel] : 0.0;
+        ChRec R2 = ch_read_rec(L, 1 < last ? 1 : last);
+        ChOps E2 = ch_read_ops(L, R2);
+        ChRec R3 = ch_read_rec(L, 2 < last ? 2 : last);
+        double vprev = 0.0;
+        for (int b = 0; b < nblk && !L->abort; b++) {
+            // the look-ahead of this block's steps reaches three steps into the next block
+#ifdef BLU_PROFILE
+            const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            wait_block(b + 1);
+#ifdef BLU_PROFILE
+            t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
+#endif
+            const int s_end = (b + 1) * CH_SB < nsteps ? (b + 1) * CH_SB : nsteps;
+            for (int s = b * CH_SB; s < s_end; s++) {
+                // ahead: window operands of step s+1, entries of s+2, record of s+3
+                const double xw2 = E2.sel >= 0 ? L->xwin[E2.sel] : 0.0;
+                const ChOps E3 = ch_read_ops(L, R3);
+                const ChRec R4 = ch_read_rec(L, s + 3 < last ? s + 3 : last);
+                // step s
+                double acc = INIT_OWN ? R1.own : 0.0;
+                if (R1.n > 0) {
+                    const double x = E1.sel == CH_SEL_PREV ? vprev : (E1.sel >= 0 ? xw1 : E1.xv);
+                    acc = ch_accumulate<SUB>(acc, lane < R1.n ? __dmul_rn(x, E1.val) : 0.0, R1.n);
+                } else if (R1.n < 0) { // long step: straight from global memory
+                    const ChMeta M = ad.meta(R1.k);
+                    for (int o = 0; o < M.len; o += 64) {
+                        ChEnt E;
+                        E.pos = 0;
+                        E.gidx = 0;
+                        E.val = 0.0;
+                        const int nn = M.len - o < 64 ? M.len - o : 64;
+                        if (lane < nn) E = ad.ent(R1.k, M.b, o + lane);
+                        acc = ch_accumulate<SUB>(acc, lane < nn ? __dmul_rn(out[E.gidx], E.val) : 0.0, nn);
+                    }
+                }
+                const double v = f(R1.k, R1.n != 0, acc, R1.own, R1.diag);
+                if (lane == 0) {
+                    L->xwin[R1.k & (CH_W - 1)] = v;
+                    out[R1.w] = v;
+                }
+                vprev = v;
+                R1 = R2;
+                E1 = E2;
+                xw1 = xw2;
+                R2 = R3;
+                E2 = E3;
+                R3 = R4;
+            }
+            // block finished: drain the stores, publish (R1 is the first step of the next block now)
+#ifdef BLU_PROFILE
+            const long long td0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            ch_vm_drain();
+#ifdef BLU_PROFILE
+            t_drain += (long long)__builtin_amdgcn_s_memtime() - td0;
+#endif
+            ch_lds_fence();
+            if (lane == 0 && s_end < nsteps) {
+                L->chain_eb = R1.eb;
+                L->chain_done = b + 1;
+            }
+        }
+        ch_vm_drain();
+#ifdef BLU_PROFILE
+        if (lane == 0)
+            printf("chain sweep (block %d): %d steps, %.0f cycles/step, waiting for blocks %.0f, draining stores %.0f\n", (int)blockIdx.x, nsteps,
+                   (double)((long long)__builtin_amdgcn_s_memtime() - t_begin) / nsteps, (double)t_wait / nsteps, (double)t_drain / nsteps);
+#endif
+    }
+    __syncthreads();
+    return L->abort == 0; // (the code of the wait that gave up stays in L->abort for the caller's error line)
+}

@@ -18,6 +18,151 @@
 
 #include "k_sweep.h"
 
+// Second half of the statistics: norms of L and U, the residuals of both systems, matrix norms and the final
+// numbers (condest.rs:27-44, 60-76; residual_test.rs:68-152; matrix_norm.rs:8-48).
+// chain_out[0], [1] = normest_l_inv, normest_u_inv of the condest chains; lf/rf/lb/rb as the chains left them.
+//
+// stats_tail_loops: the per-column / per-row passes, thread `tid` of `nt` (one workgroup of a batch, or the grid of
+// k_stats_tail_a); returns this thread's maxima.  stats_tail_finish: the four ordered 1-norms, the reductions
+// and the final numbers, one workgroup.
+__device__ __forceinline__ void stats_tail_loops(const DevG &D, const FinishOut &O, int tid, int nt, double &nl, double &nu, double &one,
+                                                 double &inf)
+{
+    Scalars *S = D.s;
+    const int m = D.m;
+    const int rank = S->rank;
+    gdouble_p lf = D.gwork + 2 * (size_t)(m + 1), rf = D.gwork + 3 * (size_t)(m + 1), lb = D.gwork + 4 * (size_t)(m + 1),
+              rb = D.gwork + 5 * (size_t)(m + 1);
+    // ---- norms of L and U (condest.rs:27-44), 1-norm = max column sum
+    nl = 0.0;
+    nu = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        double s = 1.0; // (stage-ordered column: the reference's storage and summation order)
+        for (int p = D.lbeg[k]; p < D.lbeg[k + 1]; p++) s += fabs(D.lval[p]);
+        nl = fmax(nl, s);
+        const long long e = O.u_colptr[k + 1] - 1;
+        double t = fabs(O.u_value[e]);
+        for (long long p = O.u_colptr[k]; p < e; p++) t += fabs(O.u_value[p]);
+        nu = fmax(nu, t);
+    }
+    // ---- residuals (residual_test.rs:68-83, 110-126) and matrix norms (matrix_norm.rs), pivot coordinates:
+    // column k of the factorized matrix is column colperm[k] of B for k < rank, the unit vector e_k otherwise
+    one = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        if (k < rank) {
+            const int j = D.pcol[k];
+            double cs = 0.0, d = 0.0;
+            for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
+                const double a = D.bc_val[p];
+                cs += fabs(a);
+                d = __dadd_rn(d, __dmul_rn(lb[D.pinv[D.bc_idx[p]]], a)); // B' * lhs, column order of B
+            }
+            one = fmax(one, cs);
+            rb[k] = rb[k] - d;
+        } else {
+            one = fmax(one, 1.0);
+            rb[k] = rb[k] - lb[k];
+        }
+    }
+    // forward residual rhs - B*lhs and row sums: one thread per ROW of B (bt_* = B row-wise).  The
+    // reference scatters column after column in pivot order (residual_test.rs:68-76, matrix_norm.rs:
+    // 26-36), so a row receives its terms ascending in the pivot position of their columns: the entries
+    // of the row are taken in that order (selection by repeated minimum; rows are short).
+    inf = 0.0;
+    for (int i = tid; i < m; i += nt) {
+        const int kr = D.pinv[i];
+        double acc = rf[kr], rsum = 0.0;
+        const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
+        if (e - b <= 256) {
+            int last = -1;
+            for (int t = b; t < e; t++) {
+                int best = 0x7fffffff, bp = -1;
+                for (int p = b; p < e; p++) {
+                    const int kc = D.qinv[D.bt_idx[p]];
+                    if (kc > last && kc < best) {
+                        best = kc;
+                        bp = p;
+                    }
+                }
+                if (bp < 0 || best >= rank) break;
+                const double a = D.bt_val[bp];
+                acc = __dsub_rn(acc, __dmul_rn(lf[best], a));
+                rsum += fabs(a);
+                last = best;
+            }
+        } else { // a very long row: storage order (the sums then agree with the reference to rounding only)
+            for (int p = b; p < e; p++) {
+                const int kc = D.qinv[D.bt_idx[p]];
+                if (kc < rank) {
+                    const double a = D.bt_val[p];
+                    acc = __dsub_rn(acc, __dmul_rn(lf[kc], a));
+                    rsum += fabs(a);
+                }
+            }
+        }
+        if (kr >= rank) {
+            acc = acc - lf[kr];
+            rsum += 1.0;
+        }
+        rf[kr] = acc;
+        inf = fmax(inf, rsum); // infinity norm = max row sum of |B|
+    }
+}
+__device__ __forceinline__ void stats_tail_finish(const DevG &D, double (*red)[40], double *chain_out, double nl, double nu, double one, double inf)
+{
+    Scalars *S = D.s;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id(), nw = num_waves();
+    const int m = D.m;
+    gdouble_p lf = D.gwork + 2 * (size_t)(m + 1), rf = D.gwork + 3 * (size_t)(m + 1), lb = D.gwork + 4 * (size_t)(m + 1),
+              rb = D.gwork + 5 * (size_t)(m + 1);
+    // the four 1-norms (residual_test.rs:7-13: a sequential sum over the ROW indices 0..m-1): one wave
+    // each, 64 terms fetched together and added in lane order
+    for (int q = 0; q < 4; q++) {
+        if (w != (nw >= 4 ? q : 0)) continue;
+        gdouble_p vec = q == 0 ? lf : (q == 1 ? rf : (q == 2 ? lb : rb));
+        double s = 0.0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const int n = m - i0 < 64 ? m - i0 : 64;
+            s = wave_ordered_sum(i < m ? fabs(vec[D.pinv[i]]) : 0.0, n, s);
+        }
+        if (lane == 0) chain_out[4 + q] = s;
+    }
+    // workgroup reductions: maxima
+    double vals[8] = {0.0, 0.0, 0.0, 0.0, nl, nu, one, inf};
+    for (int q = 4; q < 8; q++) {
+        double v = vals[q];
+        v = wave_max_d(v);
+        if (lane == 0) red[q & 3][w] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double a = red[q & 3][0];
+            for (int ww = 1; ww < nw; ww++) a = fmax(a, red[q & 3][ww]);
+            chain_out[4 + q] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double nf = chain_out[4], nrf = chain_out[5], nb = chain_out[6], nrb = chain_out[7];
+        S->norm_l = chain_out[8];
+        S->norm_u = chain_out[9];
+        S->onenorm = chain_out[10];
+        S->infnorm = chain_out[11];
+        S->normest_l_inv = chain_out[0];
+        S->normest_u_inv = chain_out[1];
+        S->condest_l = chain_out[8] * chain_out[0];
+        S->condest_u = chain_out[9] * chain_out[1];
+        S->residual_test = fmax(nrf / ((double)m + chain_out[10] * nf), nrb / ((double)m + chain_out[11] * nb));
+    }
+}
+__device__ __forceinline__ void stats_tail(const DevG &D, const FinishOut &O, double (*red)[40], double *chain_out)
+{
+    double nl, nu, one, inf;
+    stats_tail_loops(D, O, threadIdx.x, blockDim.x, nl, nu, one, inf);
+    __syncthreads();
+    stats_tail_finish(D, red, chain_out, nl, nu, one, inf);
+}
+
 __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
 {
     const DevG D(Ds[blockIdx.x]);
@@ -126,122 +271,7 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
     }
     __syncthreads();
 
-    // ---- norms of L and U (condest.rs:27-44), 1-norm = max column sum
-    double nl = 0.0, nu = 0.0;
-    for (int k = tid; k < m; k += nt) {
-        double s = 1.0; // (stage-ordered column: the reference's storage and summation order)
-        for (int p = D.lbeg[k]; p < D.lbeg[k + 1]; p++) s += fabs(D.lval[p]);
-        nl = fmax(nl, s);
-        const long long e = O.u_colptr[k + 1] - 1;
-        double t = fabs(O.u_value[e]);
-        for (long long p = O.u_colptr[k]; p < e; p++) t += fabs(O.u_value[p]);
-        nu = fmax(nu, t);
-    }
-    // ---- residuals (residual_test.rs:68-83, 110-126) and matrix norms (matrix_norm.rs), pivot coordinates:
-    // column k of the factorized matrix is column colperm[k] of B for k < rank, the unit vector e_k otherwise
-    for (int i = tid; i < m; i += nt) rs[i] = 0.0;
-    __syncthreads();
-    double one = 0.0;
-    for (int k = tid; k < m; k += nt) {
-        if (k < rank) {
-            const int j = D.pcol[k];
-            double cs = 0.0, d = 0.0;
-            for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
-                const double a = D.bc_val[p];
-                cs += fabs(a);
-                d = __dadd_rn(d, __dmul_rn(lb[D.pinv[D.bc_idx[p]]], a)); // B' * lhs, column order of B
-            }
-            one = fmax(one, cs);
-            rb[k] = rb[k] - d;
-        } else {
-            one = fmax(one, 1.0);
-            rb[k] = rb[k] - lb[k];
-        }
-    }
-    // forward residual rhs - B*lhs and row sums: one thread per ROW of B (bt_* = B row-wise).  The
-    // reference scatters column after column in pivot order (residual_test.rs:68-76, matrix_norm.rs:
-    // 26-36), so a row receives its terms ascending in the pivot position of their columns: the entries
-    // of the row are taken in that order (selection by repeated minimum; rows are short).
-    for (int i = tid; i < m; i += nt) {
-        const int kr = D.pinv[i];
-        double acc = rf[kr], rsum = 0.0;
-        const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
-        if (e - b <= 256) {
-            int last = -1;
-            for (int t = b; t < e; t++) {
-                int best = 0x7fffffff, bp = -1;
-                for (int p = b; p < e; p++) {
-                    const int kc = D.qinv[D.bt_idx[p]];
-                    if (kc > last && kc < best) {
-                        best = kc;
-                        bp = p;
-                    }
-                }
-                if (bp < 0 || best >= rank) break;
-                const double a = D.bt_val[bp];
-                acc = __dsub_rn(acc, __dmul_rn(lf[best], a));
-                rsum += fabs(a);
-                last = best;
-            }
-        } else { // a very long row: storage order (the sums then agree with the reference to rounding only)
-            for (int p = b; p < e; p++) {
-                const int kc = D.qinv[D.bt_idx[p]];
-                if (kc < rank) {
-                    const double a = D.bt_val[p];
-                    acc = __dsub_rn(acc, __dmul_rn(lf[kc], a));
-                    rsum += fabs(a);
-                }
-            }
-        }
-        if (kr >= rank) {
-            acc = acc - lf[kr];
-            rsum += 1.0;
-        }
-        rf[kr] = acc;
-        rs[i] = rsum;
-    }
-    __syncthreads();
-    // the four 1-norms (residual_test.rs:7-13: a sequential sum over the ROW indices 0..m-1): one wave
-    // each, 64 terms fetched together and added in lane order
-    for (int q = 0; q < 4; q++) {
-        if (w != (nw >= 4 ? q : 0)) continue;
-        gdouble_p vec = q == 0 ? lf : (q == 1 ? rf : (q == 2 ? lb : rb));
-        double s = 0.0;
-        for (int i0 = 0; i0 < m; i0 += 64) {
-            const int i = i0 + lane;
-            const int n = m - i0 < 64 ? m - i0 : 64;
-            s = wave_ordered_sum(i < m ? fabs(vec[D.pinv[i]]) : 0.0, n, s);
-        }
-        if (lane == 0) chain_out[4 + q] = s;
-    }
-    double inf = 0.0;
-    for (int k = tid; k < m; k += nt) inf = fmax(inf, rs[k]);
-    // workgroup reductions: maxima
-    double vals[8] = {0.0, 0.0, 0.0, 0.0, nl, nu, one, inf};
-    for (int q = 4; q < 8; q++) {
-        double v = vals[q];
-        v = wave_max_d(v);
-        if (lane == 0) red[q & 3][w] = v;
-        __syncthreads();
-        if (tid == 0) {
-            double a = red[q & 3][0];
-            for (int ww = 1; ww < nw; ww++) a = q < 4 ? a + red[q & 3][ww] : fmax(a, red[q & 3][ww]);
-            chain_out[4 + q] = a;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double nf = chain_out[4], nrf = chain_out[5], nb = chain_out[6], nrb = chain_out[7];
-        S->norm_l = chain_out[8];
-        S->norm_u = chain_out[9];
-        S->onenorm = chain_out[10];
-        S->infnorm = chain_out[11];
-        S->normest_l_inv = chain_out[0];
-        S->normest_u_inv = chain_out[1];
-        S->condest_l = chain_out[8] * chain_out[0];
-        S->condest_u = chain_out[9] * chain_out[1];
-        S->residual_test = fmax(nrf / ((double)m + chain_out[10] * nf), nrb / ((double)m + chain_out[11] * nb));
-    }
+    stats_tail(D, O, red, chain_out);
     // restore the all-zero invariant of the pivot_any work area
     const size_t ng = (size_t)7 * (m + 1);
     for (size_t e = tid; e < ng; e += nt) D.gwork[e] = 0.0;
