@@ -769,6 +769,24 @@ extern "C" int blu_hip_dbg_set_stop(blu_hip *h, int64_t stop_at)
     return BLU_OK;
 }
 // 1 = skip the statistics tail of factorize() (condest, residual_test); default 0 = compute, as the reference
+#ifdef BLU_STATS_DEBUG
+extern "C" int blu_hip_dbg_get_rows(blu_hip *h, int *lt_ptr, int *lt_idx, double *lt_val, int *ur_len, int *ur_pos, double *ur_val, int *ubeg)
+{
+    const size_t M = (size_t)h->m, ln = (size_t)h->hs.lused, un = (size_t)h->hs.uused;
+    bool ok = hipMemcpy(lt_ptr, h->sw.lt_ptr, (M + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(lt_idx, h->sw.lt_idx, ln * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(lt_val, h->sw.lt_val, ln * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(ur_len, h->ur_len, M * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(ur_pos, h->ur_pos, un * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(ur_val, h->ur_val, un * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(ubeg, h->D.ubeg, (M + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    return ok ? 0 : -1;
+}
+extern "C" int blu_hip_dbg_get_gwork(blu_hip *h, double *out, int64_t n)
+{
+    return hipMemcpy(out, h->D.gwork, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int blu_hip_set_skip_stats(blu_hip *h, int on)
 {
     if (!h) return BLU_ERROR_ARGUMENT_MISSING;

@@ -211,16 +211,18 @@ struct ChOps {
     double val, xv;
     int sel;
 };
+// (the four integers stay in vector registers while the record travels through the look-ahead stages: turning them
+// into scalars right after the LDS read would make the wave wait for the read in the middle of every step)
 __device__ __forceinline__ ChRec ch_read_rec(ChainLds *L, int s)
 {
     const int sl = s & (CH_CS - 1);
     const ChRecA a = L->ra[sl];
     const ChRecB b = L->rb[sl];
     ChRec R;
-    R.n = __builtin_amdgcn_readfirstlane(a.n);
-    R.eb = __builtin_amdgcn_readfirstlane(a.eb);
-    R.w = __builtin_amdgcn_readfirstlane(a.w);
-    R.k = __builtin_amdgcn_readfirstlane(a.k);
+    R.n = a.n;
+    R.eb = a.eb;
+    R.w = a.w;
+    R.k = a.k;
     R.diag = b.diag;
     R.own = b.own;
     return R;
@@ -322,26 +324,28 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
                 const ChOps E3 = ch_read_ops(L, R3);
                 const ChRec R4 = ch_read_rec(L, s + 3 < last ? s + 3 : last);
                 // step s
+                const int n1 = __builtin_amdgcn_readfirstlane(R1.n), k1 = __builtin_amdgcn_readfirstlane(R1.k),
+                          w1 = __builtin_amdgcn_readfirstlane(R1.w);
                 double acc = INIT_OWN ? R1.own : 0.0;
-                if (R1.n > 0) {
+                if (n1 > 0) {
                     const double x = E1.sel == CH_SEL_PREV ? vprev : (E1.sel >= 0 ? xw1 : E1.xv);
-                    acc = ch_accumulate<SUB>(acc, lane < R1.n ? __dmul_rn(x, E1.val) : 0.0, R1.n);
-                } else if (R1.n < 0) { // long step: straight from global memory
-                    const ChMeta M = ad.meta(R1.k);
+                    acc = ch_accumulate<SUB>(acc, lane < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
+                } else if (n1 < 0) { // long step: straight from global memory
+                    const ChMeta M = ad.meta(k1);
                     for (int o = 0; o < M.len; o += 64) {
                         ChEnt E;
                         E.pos = 0;
                         E.gidx = 0;
                         E.val = 0.0;
                         const int nn = M.len - o < 64 ? M.len - o : 64;
-                        if (lane < nn) E = ad.ent(R1.k, M.b, o + lane);
+                        if (lane < nn) E = ad.ent(k1, M.b, o + lane);
                         acc = ch_accumulate<SUB>(acc, lane < nn ? __dmul_rn(out[E.gidx], E.val) : 0.0, nn);
                     }
                 }
-                const double v = f(R1.k, R1.n != 0, acc, R1.own, R1.diag);
+                const double v = f(k1, n1 != 0, acc, R1.own, R1.diag);
                 if (lane == 0) {
-                    L->xwin[R1.k & (CH_W - 1)] = v;
-                    out[R1.w] = v;
+                    L->xwin[k1 & (CH_W - 1)] = v;
+                    out[w1] = v;
                 }
                 vprev = v;
                 R1 = R2;

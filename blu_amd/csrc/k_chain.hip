@@ -110,7 +110,7 @@ __device__ __forceinline__ void rows_body(const DevG &D, const RowsWs &R, Scope 
                     n++;
                 }
             }
-            if (n > 24 && n <= WSORT_MAX) D.iw2[m - 1 - atomicAdd(sc.ctr(1), 1)] = k;
+            if (n > 24 && n <= WSORT_MAX) D.iw1[atomicAdd(sc.ctr(1), 1)] = k; // (its own queue: a row can be in both)
             else insertion_sort_ik<true>(R.ur_pos, R.ur_val, b, b + n);
         }
         R.ur_len[k] = n;
@@ -119,13 +119,16 @@ __device__ __forceinline__ void rows_body(const DevG &D, const RowsWs &R, Scope 
     {
         const int nl = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nu = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BLU_STATS_DEBUG
+        if (sc.leader()) printf("k_rows_grid: medium L rows %d, medium U rows %d, rank %d, m %d\n", nl, nu, rank, m);
+#endif
         for (int r = sc.wid(); r < nl + nu; r += sc.nw()) {
             if (r < nl) {
                 const int i = D.iw2[r];
                 wave_sort_segment_ik<false>(R.lt_idx, R.lt_val, R.lt_ptr[i], R.lt_ptr[i + 1], &lds_k[wave_id() * WSORT_MAX],
                                             &lds_v[wave_id() * WSORT_MAX]);
             } else {
-                const int k = D.iw2[m - 1 - (r - nl)];
+                const int k = D.iw1[r - nl];
                 wave_sort_segment_ik<true>(R.ur_pos, R.ur_val, D.ubeg[k], D.ubeg[k] + R.ur_len[k], &lds_k[wave_id() * WSORT_MAX],
                                            &lds_v[wave_id() * WSORT_MAX]);
             }

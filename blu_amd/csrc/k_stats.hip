@@ -271,6 +271,9 @@ __global__ void __launch_bounds__(1024) k_stats(DevLU *Ds, FinishOut *Os)
     }
     __syncthreads();
 
+#ifdef BLU_STATS_DEBUG
+    return; // the work vectors of the chains stay in gwork (blu_hip_dbg_get_gwork)
+#endif
     stats_tail(D, O, red, chain_out);
     // restore the all-zero invariant of the pivot_any work area
     const size_t ng = (size_t)7 * (m + 1);

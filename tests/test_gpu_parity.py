@@ -370,8 +370,10 @@ def test_general_paths_only_matches_fast_paths(blu, oracle):
     assert a.stat(54) > 0 and a.stat(K.STAT_NSEARCH_PIVOT) == b.stat(K.STAT_NSEARCH_PIVOT)
 
 
+# (m = 6000: longer than the LDS window of the chain pipeline, k_chain.h -- operands gathered by the helper waves -- and
+# with lines of more than 64 entries, which the chain wave takes straight from global memory)
 @pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1000, 10, 12, 1.0, 11, 0.2),
-                                  (1500, 8, 16, 0.2, 3, 1.0)], ids=lambda s: "m%d" % s[0])
+                                  (1500, 8, 16, 0.2, 3, 1.0), (6000, 8, 8, 0.5, 1, 0.3)], ids=lambda s: "m%d" % s[0])
 @pytest.mark.parametrize("block", [1024, 128])
 def test_statistics_tail(blu, oracle, spec, block):
     """condest(L), condest(U), matrix norms, residual_test (factorize.rs:121-147): every
@@ -491,7 +493,8 @@ def test_solve_sparse_golden_fixtures(blu):
             assert np.array_equal(il, g[key + "_ilhs"]) and np.array_equal(h.lhs[il], g[key + "_xlhs"]), key
 
 
-@pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1500, 8, 16, 0.2, 3, 1.0)], ids=lambda s: "m%d" % s[0])
+@pytest.mark.parametrize("spec", [(300, 5, 4, 0.5, 1, 0.3), (2000, 8, 8, 0.5, 1, 0.3), (1500, 8, 16, 0.2, 3, 1.0), (6000, 8, 8, 0.5, 1, 0.3)],
+                         ids=lambda s: "m%d" % s[0])
 def test_solve_dense_identical_to_oracle(blu, oracle, spec):
     """solve_dense keeps the reference's operation order (solve_dense.rs:32-119): bit-identical results,
     both systems, full-rank and rank-deficient factors."""
@@ -509,3 +512,27 @@ def test_solve_dense_identical_to_oracle(blu, oracle, spec):
             b = rng.standard_normal(m)
             assert np.array_equal(g.solve_dense(b, trans), o.solve_dense(b, trans)), (singular, trans)
 
+
+
+def test_chain_pipeline_and_one_workgroup_kernels_agree(blu, oracle, monkeypatch):
+    """A single factorize runs its statistics and solve_dense on the chain pipeline (k_chain.hip); a batch, or a
+    device without the LDS for it, on one workgroup per matrix (k_stats.hip, k_solve.hip).  Same numbers, bit for bit."""
+    cp, ri, v = oracle.gen_lp_basis(6000, 8, 8, 0.5, 1, 0.3)
+    m = 6000
+    a = blu.BLU(m, len(ri))
+    monkeypatch.setenv("BLU_HIP_NO_CHAIN", "1")
+    b = blu.BLU(m, len(ri))
+    monkeypatch.delenv("BLU_HIP_NO_CHAIN")
+    assert a.factorize(cp[:-1], cp[1:], ri, v) == b.factorize(cp[:-1], cp[1:], ri, v) == K.OK
+    assert a.stat(108) > 0.0 and b.stat(108) == 0.0  # k_rows_grid ran for the first handle only
+    for c in FSTATS + ("RESIDUAL_TEST",):
+        assert a.stat(getattr(K, "STAT_" + c)) == b.stat(getattr(K, "STAT_" + c)), c
+    rhs = np.random.default_rng(3).standard_normal(m)
+    for trans in "NT":
+        assert np.array_equal(a.solve_dense(rhs, trans), b.solve_dense(rhs, trans)), trans
+    # solve_sparse reads the row-wise L the chain path built
+    ir = np.array([5, 77, 4000], dtype=np.uint64)
+    xr = np.array([1.0, -2.0, 0.5])
+    for trans in "NT":
+        assert a.solve_sparse(ir, xr, trans) == b.solve_sparse(ir, xr, trans) == K.OK
+        assert a.nzlhs == b.nzlhs and np.array_equal(a.ilhs[:a.nzlhs], b.ilhs[:b.nzlhs]) and np.array_equal(a.lhs, b.lhs), trans
