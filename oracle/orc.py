@@ -30,7 +30,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liborc.so")
+        # ORC_LIB: another build of the same sources (tools/oracle_sanitize.sh: AddressSanitizer + UBSan)
+        path = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborc.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
