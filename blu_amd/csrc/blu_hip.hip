@@ -674,8 +674,14 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     // a factorization whose row-wise copies exist (a single factorize on a device with the LDS for it): the chain pipeline
     if (h->chain_ok && h->rows_for_nfact == h->nfactorize && h->lt_for_nfact == h->nfactorize) {
         hipLaunchKernelGGL(k_solve_dense_chain, dim3(1), dim3(CHAIN_THREADS), sizeof(ChainLds), h->stream, h->dD, h->dO, rows_ws_of(h), h->d_rhs,
-                           h->d_lhs, tr);
+                           h->d_lhs, tr, &h->gw->ctr[7]);
         if (!hip_ok(h, hipStreamSynchronize(h->stream), "k_solve_dense_chain")) return BLU_ERROR_DEVICE;
+        int defect = 0;
+        if (!hip_ok(h, hipMemcpy(&defect, &h->gw->ctr[7], sizeof(int), hipMemcpyDeviceToHost), "d2h defect")) return BLU_ERROR_DEVICE;
+        if (defect) { // a bounded wait of the chain pipeline gave up (k_chain.h): never a valid state
+            h->err = "k_solve_dense_chain: internal wait abandoned, code " + std::to_string(defect);
+            return BLU_ERROR_DEVICE;
+        }
         if (!hip_ok(h, hipMemcpy(lhs, h->d_lhs, M * 8, hipMemcpyDeviceToHost), "d2h lhs")) return BLU_ERROR_DEVICE;
         return BLU_OK;
     }

@@ -36,6 +36,8 @@
 #define CH_CS (CH_SB * CH_NB)    // step ring
 #define CH_CE 4096               // entry ring (two full blocks of 64-entry steps)
 #define CH_W 2048                // window of results kept in LDS (positions)
+#define CH_FAR 320               // a producer this many steps back is final and visible when a helper stages (> CH_CS)
+#define CH_HAS 0x10000           // record: the step has entries (some or all may have gone into `init` already)
 #define CH_HT 16                 // hand-off ring of entry bases
 #define CH_SEL_FAR (-1)          // operand: the helper's gathered value
 #define CH_SEL_PREV (-2)         // operand: the previous step's result (register)
@@ -55,6 +57,7 @@ struct ChainLds {
     double xwin[CH_W];
     ChRecA ra[CH_CS];
     ChRecB rb[CH_CS];
+    double rinit[CH_CS]; // the accumulator's start: own value or 0, plus the leading terms the helper has added already
     long long s_b[CH_CS];
     volatile int blk_ready[CH_NB];
     volatile int eb_tag[CH_HT];
@@ -100,7 +103,7 @@ __device__ __forceinline__ double ch_load_final(gdouble_p p)
 }
 
 // ---- helper side: stage block b ---------------------------------------------------------------------------
-template <class A>
+template <bool INIT_OWN, bool SUB, class A>
 __device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, int k0, int dir, int nsteps, gdouble_p out)
 {
     const int lane = lane_id();
@@ -134,7 +137,7 @@ __device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, 
     if (mine) {
         const int sl = slot0 + lane;
         ChRecA a;
-        a.n = M.len <= 64 ? M.len : -1;
+        a.n = M.len <= 64 ? (M.len > 0 ? (M.len | CH_HAS) : 0) : -1;
         a.eb = base + off;
         a.w = M.w;
         a.k = k;
@@ -143,6 +146,7 @@ __device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, 
         bq.diag = M.diag;
         bq.own = M.own;
         L->rb[sl] = bq;
+        L->rinit[sl] = INIT_OWN ? M.own : 0.0;
         L->s_b[sl] = M.b;
     }
     ch_lds_fence();
@@ -181,7 +185,7 @@ __device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, 
         for (int u = 0; u < 4; u++) {
             const int kk = L->ra[slot0 + tt[u]].k;
             const int d = (kk - E[u].pos) * dir;
-            far[u] = ok[u] && d >= CH_W;
+            far[u] = ok[u] && d >= CH_FAR;
             xo[u] = 0.0;
             if (far[u]) xo[u] = ch_load_final(out + E[u].gidx);
         }
@@ -199,13 +203,34 @@ __device__ __forceinline__ void ch_stage_block(const A &ad, ChainLds *L, int b, 
         }
     }
     ch_lds_fence();
+    // The leading terms of a step whose producers are that far back are final: this lane (one per step) adds them in
+    // the step's order, with the chain wave's two roundings per term, and the chain wave starts behind them.  (Lines
+    // sorted in sweep order -- canonical U columns, row-wise L, sorted U rows -- have all such terms in front.)
+    if (mine && M.len > 0 && M.len <= 64) {
+        const int sl = slot0 + lane;
+        const int eb = base + off;
+        double acc = INIT_OWN ? M.own : 0.0;
+        int p = 0;
+        while (p < M.len && L->sel[(eb + p) & (CH_CE - 1)] == CH_SEL_FAR) {
+            const ChOpsV ov = L->ev[(eb + p) & (CH_CE - 1)];
+            const double term = __dmul_rn(ov.xv, ov.val);
+            acc = SUB ? __dsub_rn(acc, term) : __dadd_rn(acc, term);
+            p++;
+        }
+        if (p > 0) {
+            L->ra[sl].n = (M.len - p) | CH_HAS;
+            L->ra[sl].eb = eb + p;
+            L->rinit[sl] = acc;
+        }
+    }
+    ch_lds_fence();
     if (lane == 0) L->blk_ready[b & (CH_NB - 1)] = b + 1;
 }
 
 // ---- chain side -------------------------------------------------------------------------------------------
 struct ChRec {
-    int n, eb, w, k;
-    double diag, own;
+    int n, eb, w, k; // n: entries left for the chain wave | CH_HAS, or -1 (long step)
+    double diag, own, init;
 };
 struct ChOps {
     double val, xv;
@@ -225,6 +250,7 @@ __device__ __forceinline__ ChRec ch_read_rec(ChainLds *L, int s)
     R.k = a.k;
     R.diag = b.diag;
     R.own = b.own;
+    R.init = L->rinit[sl];
     return R;
 }
 __device__ __forceinline__ ChOps ch_read_ops(ChainLds *L, const ChRec &R)
@@ -233,7 +259,7 @@ __device__ __forceinline__ ChOps ch_read_ops(ChainLds *L, const ChRec &R)
     E.val = 0.0;
     E.xv = 0.0;
     E.sel = CH_SEL_FAR;
-    if (lane_id() < R.n) {
+    if (lane_id() < (R.n & (CH_HAS - 1)) && R.n > 0) {
         const int r = (R.eb + lane_id()) & (CH_CE - 1);
         const ChOpsV v = L->ev[r];
         E.val = v.val;
@@ -269,6 +295,7 @@ __device__ __forceinline__ double ch_accumulate(double acc, double prod, int n)
 //   INIT_OWN: the accumulator starts at the step's own value (scatter-form loops of the reference), else at 0
 //   SUB:      terms are subtracted, else added
 //   f(k, has_entries, acc, own, diag) -> the step's result, stored to out[w] and the window; f may store more
+// The helpers add the leading terms whose producers are at least CH_FAR steps back (ch_stage_block).
 // On return every store of the sweep has completed and the workgroup is synchronised; false: abandoned (defect).
 template <bool INIT_OWN, bool SUB, class A, class F>
 __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, int dir, int nsteps, gdouble_p out, F f)
@@ -284,7 +311,7 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
     }
     __syncthreads();
     if (w > 0) {
-        for (int b = w - 1; b < nblk && !L->abort; b += nw - 1) ch_stage_block(ad, L, b, k0, dir, nsteps, out);
+        for (int b = w - 1; b < nblk && !L->abort; b += nw - 1) ch_stage_block<INIT_OWN, SUB>(ad, L, b, k0, dir, nsteps, out);
     } else if (nsteps > 0) {
 #ifdef BLU_PROFILE
         long long t_wait = 0, t_drain = 0;
@@ -324,9 +351,10 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
                 const ChOps E3 = ch_read_ops(L, R3);
                 const ChRec R4 = ch_read_rec(L, s + 3 < last ? s + 3 : last);
                 // step s
-                const int n1 = __builtin_amdgcn_readfirstlane(R1.n), k1 = __builtin_amdgcn_readfirstlane(R1.k),
+                const int nf = __builtin_amdgcn_readfirstlane(R1.n), k1 = __builtin_amdgcn_readfirstlane(R1.k),
                           w1 = __builtin_amdgcn_readfirstlane(R1.w);
-                double acc = INIT_OWN ? R1.own : 0.0;
+                const int n1 = nf < 0 ? -1 : (nf & (CH_HAS - 1));
+                double acc = R1.init;
                 if (n1 > 0) {
                     const double x = E1.sel == CH_SEL_PREV ? vprev : (E1.sel >= 0 ? xw1 : E1.xv);
                     acc = ch_accumulate<SUB>(acc, lane < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
@@ -342,7 +370,7 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
                         acc = ch_accumulate<SUB>(acc, lane < nn ? __dmul_rn(out[E.gidx], E.val) : 0.0, nn);
                     }
                 }
-                const double v = f(k1, n1 != 0, acc, R1.own, R1.diag);
+                const double v = f(k1, nf != 0, acc, R1.own, R1.diag);
                 if (lane == 0) {
                     L->xwin[k1 & (CH_W - 1)] = v;
                     out[w1] = v;

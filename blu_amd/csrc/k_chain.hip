@@ -484,7 +484,9 @@ struct ChSolveLStage {
     }
 };
 
-__global__ void __launch_bounds__(CHAIN_THREADS) k_solve_dense_chain(DevLU *Ds, FinishOut *Os, RowsWs R, const double *rhs, double *lhs, int trans)
+// *defect: 0, or 9100 + the code of the bounded wait that gave up (the host then fails the call)
+__global__ void __launch_bounds__(CHAIN_THREADS) k_solve_dense_chain(DevLU *Ds, FinishOut *Os, RowsWs R, const double *rhs, double *lhs, int trans,
+                                                                     int *defect)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
     ChainLds *L = (ChainLds *)ch_smem;
@@ -510,5 +512,5 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_solve_dense_chain(DevLU *Ds, 
         const ChSolveLStage A2{D.lbeg, D.lidx, D.pinv, D.prow, D.lval, x_out};
         ok = ok && chain_sweep<false, false>(A2, L, m - 1, -1, m, x_out, sub_dot);
     }
-    if (!ok && threadIdx.x == 0) set_error(D.s, ST_ERROR, 9100 + L->abort);
+    if (threadIdx.x == 0) *defect = ok ? 0 : 9100 + L->abort;
 }

@@ -120,11 +120,16 @@ __device__ __forceinline__ void stats_tail_finish(const DevG &D, double (*red)[4
     for (int q = 0; q < 4; q++) {
         if (w != (nw >= 4 ? q : 0)) continue;
         gdouble_p vec = q == 0 ? lf : (q == 1 ? rf : (q == 2 ? lb : rb));
+        // (two chunks in flight: the gather of the next 64 terms is issued before the current 64 are added)
+        const auto term = [&](int i0) { return i0 + lane < m ? fabs(vec[D.pinv[i0 + lane]]) : 0.0; };
+        const auto cnt = [&](int i0) { return m - i0 < 64 ? (m - i0 < 0 ? 0 : m - i0) : 64; };
         double s = 0.0;
-        for (int i0 = 0; i0 < m; i0 += 64) {
-            const int i = i0 + lane;
-            const int n = m - i0 < 64 ? m - i0 : 64;
-            s = wave_ordered_sum(i < m ? fabs(vec[D.pinv[i]]) : 0.0, n, s);
+        double a = term(0);
+        for (int i0 = 0; i0 < m; i0 += 128) {
+            const double b = term(i0 + 64);
+            s = wave_ordered_sum(a, cnt(i0), s);
+            a = term(i0 + 128);
+            s = wave_ordered_sum(b, cnt(i0 + 64), s);
         }
         if (lane == 0) chain_out[4 + q] = s;
     }

@@ -121,10 +121,20 @@ struct LStage {
 __device__ __forceinline__ double wave_ordered_sum(double prod, int n, double acc)
 {
     const unsigned lo = (unsigned)__double_as_longlong(prod), hi = (unsigned)(__double_as_longlong(prod) >> 32);
-    for (int t = 0; t < n; t++) {
-        const unsigned a = __builtin_amdgcn_readlane(lo, t), b = __builtin_amdgcn_readlane(hi, t);
-        acc = __dadd_rn(acc, __longlong_as_double((long long)(((unsigned long long)b << 32) | a)));
+#define WOS_TERM(T)                                                                                           \
+    {                                                                                                         \
+        const unsigned a_ = __builtin_amdgcn_readlane(lo, (T)), b_ = __builtin_amdgcn_readlane(hi, (T));      \
+        acc = __dadd_rn(acc, __longlong_as_double((long long)(((unsigned long long)b_ << 32) | a_)));         \
     }
+    int t = 0;
+    for (; t + 4 <= n; t += 4) { // (unrolled: two v_readlane and the add per term, no loop overhead)
+        WOS_TERM(t)
+        WOS_TERM(t + 1)
+        WOS_TERM(t + 2)
+        WOS_TERM(t + 3)
+    }
+    for (; t < n; t++) WOS_TERM(t)
+#undef WOS_TERM
     return acc;
 }
 
