@@ -52,3 +52,29 @@ def _last_started(log):
         return lines[-1][6:] if lines else "(none)"
     except OSError:
         return "(no log)"
+
+
+# ---- the update path (tools/fuzz_update_gpu.py): lock step with the CPU twin on random bases and replacement sequences
+UPD_SLICES = [(4242, 60 * i, 60) for i in range(8)]
+
+
+@pytest.mark.parametrize("seed,start,count", UPD_SLICES, ids=lambda v: str(v))
+def test_update_fuzz_slice(seed, start, count):
+    if _stop["why"]:
+        pytest.skip("not started: " + _stop["why"])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzzupd_s%d_%04d.log" % (seed, start))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_update_gpu.py"), "--seed", str(seed), "--start", str(start),
+           "--count", str(count), "--log", log]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    except subprocess.TimeoutExpired:
+        _stop["why"] = "update slice (%d, %d) hung; last case started: %s" % (seed, start, _last_started(log))
+        pytest.fail(_stop["why"])
+    text = r.stdout.decode(errors="replace")
+    if r.returncode < 0 or r.returncode >= 124:
+        _stop["why"] = "update slice (%d, %d) was killed (rc %d); last case started: %s" % (seed, start, r.returncode, _last_started(log))
+        pytest.fail(_stop["why"] + "\n" + text[-2000:])
+    assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
+    assert ("all %d update cases of seed %d from %d identical" % (count, seed, start)) in text
