@@ -150,7 +150,7 @@ static void free_all(blu_hip *h)
     dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value);
     dfree(h->ob_begin); dfree(h->ob_end); dfree(h->ob_i); dfree(h->ob_x);
     SparseWs &W = h->sw;
-    dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
+    dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.estack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
     dfree(W.xval); dfree(W.out); dfree(W.lt_ptr); dfree(W.lt_idx); dfree(W.lt_val); dfree(W.lt_cur);
     dfree(h->d_irhs); dfree(h->d_xrhs);
     dfree(h->ur_len); dfree(h->ur_pos); dfree(h->ur_val);
@@ -570,7 +570,7 @@ static int ensure_sparse_ws(blu_hip *h)
     if (h->sw_ready) return BLU_OK;
     const size_t M = (size_t)h->m;
     SparseWs &W = h->sw;
-    bool a = dalloc(h, &W.marked, M) && dalloc(h, &W.psym, M) && dalloc(h, &W.pat, M) && dalloc(h, &W.pstack, M) &&
+    bool a = dalloc(h, &W.marked, M) && dalloc(h, &W.psym, M) && dalloc(h, &W.pat, M) && dalloc(h, &W.pstack, M) && dalloc(h, &W.estack, M) &&
              dalloc(h, &W.work, M) && dalloc(h, &W.xlhs, M) && dalloc(h, &W.ilhs, M) && dalloc(h, &W.xval, M) &&
              dalloc(h, &W.out, 4) && dalloc(h, &W.lt_ptr, M + 1) && dalloc(h, &W.lt_cur, M);
     a = a && hip_ok(h, hipMemset(W.marked, 0, M * sizeof(int)), "hipMemset") &&

@@ -22,6 +22,7 @@ struct SparseWs {
     int *psym;       // m: DFS stack from the front, topological order from the back (pattern_symb)
     int *pat;        // m: pattern of the intermediate vector
     int *pstack;     // m: position stack of the DFS (the reference keeps it in work1)
+    int *estack;     // m: end of the adjacency list of each stack level (dfs_reach_wave)
     double *work;    // m, all zero between calls (work0)
     double *xlhs;    // m, all zero between calls
     int *ilhs;       // m: OUT pattern of the solution
@@ -122,19 +123,114 @@ __device__ __forceinline__ int dfs_reach(const G &g, int i, int top, int *xi, in
     return top;
 }
 
-// solve_symbolic (solve_symbolic.rs:19-40), whole wave (lane 0 works); returns top
+// The same search by the whole wave (dfs.rs:49-145: same visiting order, same output).  The lone-lane form above
+// pays a dependent global load or two for every ENTRY it looks at (~1 us each); here the 64 lanes look at 64 entries
+// of the adjacency list at once -- neighbour, its mark, and where its own list begins and ends, all issued together
+// -- and the first unvisited one (lowest lane = the one the sequential scan would stop at; marks only change through
+// this search) is descended into with its list bounds already in hand: two to four dependent loads per node VISIT
+// instead of per entry.  The top of the stack lives in registers, the levels below in an LDS ring (write-through to
+// xi / pstack / estack in global memory, which the ring is refilled from, 64 levels at a time, when a deep stack
+// unwinds past it).
+#define DFS_RING 2048
+struct DfsRing {
+    int i[DFS_RING], p[DFS_RING], e[DFS_RING];
+};
 template <class G>
-__device__ __forceinline__ int solve_symbolic(const G &g, int m, int nrhs, const int *irhs, const SparseWs &W, int M)
+__device__ __forceinline__ int dfs_reach_wave(const G &g, int i0, int top, int *xi, int *pstack, int *estack, int *marked, int M, DfsRing *R)
 {
-    int top = m;
-    if (lane_id() == 0) {
-        for (int n = 0; n < nrhs; n++) {
-            const int i = irhs[n];
-            if (W.marked[i] != M) top = dfs_reach(g, i, top, W.psym, W.pstack, W.marked, M);
+    const int lane = lane_id();
+    int head = 0, lo = 0; // ring slots of the levels lo..head-1 are valid
+    int i = i0, p = g.begin(i0), e = g.end(i0);
+    if (lane == 0) {
+        marked[i0] = M;
+        xi[0] = i0;
+    }
+    wave_mem_sync();
+    for (;;) {
+        // first unvisited neighbour of i at or behind position p
+        int child = -1, cb = 0, ce = 0, cpos = e;
+        for (int q0 = p; q0 < e; q0 += 64) {
+            const int q = q0 + lane;
+            int inext = -1, mk = M, nb = 0, ne = 0;
+            if (q < e) {
+                inext = g.node(q);
+                if (inext >= 0) {
+                    mk = marked[inext];
+                    nb = g.begin(inext);
+                    ne = g.end(inext);
+                }
+            }
+            const unsigned long long b = __ballot(inext >= 0 && mk != M);
+            if (b) {
+                const int l = __ffsll((long long)b) - 1;
+                child = wave_bcast_i(inext, l);
+                cb = wave_bcast_i(nb, l);
+                ce = wave_bcast_i(ne, l);
+                cpos = q0 + l + 1;
+                break;
+            }
+        }
+        if (child >= 0) { // descend: level `head` continues at cpos later
+            if (lane == 0) {
+                pstack[head] = cpos;
+                estack[head] = e;
+                xi[head + 1] = child;
+                marked[child] = M;
+                R->i[head & (DFS_RING - 1)] = i;
+                R->p[head & (DFS_RING - 1)] = cpos;
+                R->e[head & (DFS_RING - 1)] = e;
+            }
+            if (head - (DFS_RING - 1) > lo) lo = head - (DFS_RING - 1);
+            head++;
+            i = child;
+            p = cb;
+            e = ce;
+            wave_mem_sync();
+        } else { // node i has no unvisited neighbours
+            top--;
+            if (lane == 0) xi[top] = i;
+            head--;
+            if (head < 0) break;
+            if (head < lo) { // the stack has unwound past the ring: refill 64 levels
+                const int h = head - lane;
+                if (h >= 0) {
+                    R->i[h & (DFS_RING - 1)] = xi[h];
+                    R->p[h & (DFS_RING - 1)] = pstack[h];
+                    R->e[h & (DFS_RING - 1)] = estack[h];
+                }
+                lo = head - 63 < 0 ? 0 : head - 63;
+                wave_mem_sync();
+            }
+            i = R->i[head & (DFS_RING - 1)];
+            p = R->p[head & (DFS_RING - 1)];
+            e = R->e[head & (DFS_RING - 1)];
         }
     }
     wave_mem_sync();
-    return __shfl(top, 0);
+    return top;
+}
+
+// solve_symbolic (solve_symbolic.rs:19-40), whole wave; returns top.  The roots are taken 64 at a time: one that is
+// marked when its chunk is loaded stays marked (marks are only ever set during a symbolic phase), the others are
+// looked at again when their turn comes.
+template <class G>
+__device__ __forceinline__ int solve_symbolic(const G &g, int m, int nrhs, const int *irhs, const SparseWs &W, int M, DfsRing *R)
+{
+    const int lane = lane_id();
+    int top = m;
+    for (int n0 = 0; n0 < nrhs; n0 += 64) {
+        const int n = n0 + lane;
+        const int ir = n < nrhs ? irhs[n] : 0;
+        unsigned long long todo = __ballot(n < nrhs && W.marked[ir] != M);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int i = wave_bcast_i(ir, l);
+            if (W.marked[i] != M) top = dfs_reach_wave(g, i, top, W.psym, W.pstack, W.estack, W.marked, M, R);
+        }
+    }
+    wave_mem_sync();
+    return top;
 }
 
 // solve_triangular (solve_triangular.rs:27-136), whole wave: columns in the given order, lanes over the
@@ -212,6 +308,7 @@ __device__ __forceinline__ void sweep_nonzeros_desc(int len, const double *vec, 
 __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, SparseWs W, int nrhs, const int *irhs, const double *xrhs,
                                                      int trans, int marker, int nz_sparse)
 {
+    __shared__ DfsRing dfs_ring;
     const DevG D(Ds[0]);
     const FinishOut &O = Os[0];
     const int lane = lane_id();
@@ -227,7 +324,7 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         // ---- transposed system (solve_sparse.rs:51-179): U', then L'
         const GraphW GW{D.qinv, D.ubeg, D.uidx, D.uval, (gcll)O.u_colptr, (gcd)O.u_value, rank};
         int M = marker + 1;
-        int top = solve_symbolic(GW, m, nrhs, irhs, W, M);
+        int top = solve_symbolic(GW, m, nrhs, irhs, W, M, &dfs_ring);
         for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
         wave_mem_sync();
         nz = solve_triangular<true>(GW, m - top, W.psym + top, droptol, W.work, W.pat, u_flops);
@@ -244,7 +341,7 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         const GraphLt GT{W.lt_ptr, W.lt_idx, W.lt_val};
         if (nz <= nz_sparse) {
             M = marker + 3;
-            top = solve_symbolic(GT, m, nz, W.pat, W, M);
+            top = solve_symbolic(GT, m, nz, W.pat, W, M, &dfs_ring);
             nz = solve_triangular<false>(GT, m - top, W.psym + top, droptol, W.xlhs, W.ilhs, l_flops);
         } else { // sequential solve with L' (:159-179)
             branch = 2;
@@ -271,7 +368,7 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         // ---- forward system (solve_sparse.rs:180-346): L, then U
         const GraphL GL{D.pinv, D.lbeg, D.lidx, D.lval};
         int M = marker + 1;
-        int top = solve_symbolic(GL, m, nrhs, irhs, W, M);
+        int top = solve_symbolic(GL, m, nrhs, irhs, W, M, &dfs_ring);
         const int nz_symb = m - top;
         for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
         wave_mem_sync();
@@ -294,7 +391,7 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         const GraphU GU{D.pinv, D.prow, (gcll)O.u_colptr, (gcll)O.u_rowidx, (gcd)O.u_value};
         if (nz <= nz_sparse) {
             M = marker + 2;
-            top = solve_symbolic(GU, m, nz, W.pat, W, M);
+            top = solve_symbolic(GU, m, nz, W.pat, W, M, &dfs_ring);
             nz = solve_triangular<true>(GU, m - top, W.psym + top, droptol, W.work, W.ilhs, u_flops);
             // permute into xlhs; the pattern goes from row to column indices (:299-306)
             for (int n = lane; n < nz; n += 64) {

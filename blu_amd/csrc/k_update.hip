@@ -195,6 +195,7 @@ __device__ __forceinline__ void garbage_perm_lane0(const UpdWs &U, int m, int *m
 __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U, int mode, int want_solution, int nrhs, const int *irhs,
                                                   const double *xrhs, int trans, int marker, int nz_sparse)
 {
+    __shared__ DfsRing dfs_ring;
     const DevG D(Ds[0]);
     const int lane = lane_id();
     const int m = D.m;
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             const int ipivot = U.pmap[jpivot];
             const int jb = U.wbeg[jpivot], je = jb + U.wlen[jpivot];
             M = marker + 1;
-            top = solve_symbolic(GW, m, je - jb, U.widx + jb, W, M);
+            top = solve_symbolic(GW, m, je - jb, U.widx + jb, W, M, &dfs_ring);
             nz_symb = m - top;
             const int rput = U.rbeg[nforrest];
             if (U.rcapacity - rput < nz_symb) { // not enough room for the row eta: the host grows it and calls again
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
         } else {
             // ---- solve_sparse: U' x = rhs (solve_sparse.rs:51-106)
             M = marker + 1;
-            top = solve_symbolic(GW, m, nrhs, irhs, W, M);
+            top = solve_symbolic(GW, m, nrhs, irhs, W, M, &dfs_ring);
             for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
             wave_mem_sync();
             nz = solve_triangular<true>(GW, m - top, W.psym + top, droptol, W.work, W.pat, u_flops);
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             // ---- L' (:127-179 / solve_for_update.rs:187-245)
             if (nz <= nz_sparse) {
                 M = marker + 3;
-                top = solve_symbolic(GT, m, nz, W.pat, W, M);
+                top = solve_symbolic(GT, m, nz, W.pat, W, M, &dfs_ring);
                 nz = solve_triangular<false>(GT, m - top, W.psym + top, droptol, W.xlhs, W.ilhs, l_flops);
             } else {
                 branch = 2;
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
         // =========== forward system ===========
         // ---- L (solve_sparse.rs:180-243 / solve_for_update.rs:257-310)
         M = marker + 1;
-        top = solve_symbolic(GL, m, nrhs, irhs, W, M);
+        top = solve_symbolic(GL, m, nrhs, irhs, W, M, &dfs_ring);
         nz_symb = m - top;
         for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
         wave_mem_sync();
@@ -409,7 +410,7 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             // ---- U (:264-334 / solve_for_update.rs:363-433)
             if (nz <= nz_sparse) {
                 M = marker + 2;
-                top = solve_symbolic(GU, m, nz, W.pat, W, M);
+                top = solve_symbolic(GU, m, nz, W.pat, W, M, &dfs_ring);
                 nz = solve_triangular<true>(GU, m - top, W.psym + top, droptol, W.work, W.ilhs, u_flops);
                 for (int n = lane; n < nz; n += 64) { // permute into xlhs; the pattern goes from row to column indices
                     const int i = W.ilhs[n], j = U.qmap[i];
