@@ -167,6 +167,9 @@ __device__ __forceinline__ int dfs_reach_wave(const G &g, int i0, int top, int *
                 cb = wave_bcast_i(nb, l);
                 ce = wave_bcast_i(ne, l);
                 cpos = q0 + l + 1;
+                // marks are only ever set during a search: if nothing else in the rest of the list is unvisited now,
+                // nothing will be when the search comes back -- the level is finished, no second look
+                if ((b & ~(1ull << l)) == 0ull && q0 + 64 >= e) cpos = e;
                 break;
             }
         }
@@ -239,25 +242,76 @@ template <bool PIV, class G>
 __device__ __forceinline__ int solve_triangular(const G &g, int nz_symb, const int *psym, double droptol, double *lhs, int *pattern,
                                                 long long &flops)
 {
+    // The symbolic reach can be far longer than the numerical one (on the banded LP bases a unit vector reaches
+    // tens of thousands of nodes through the U chain while the values fall below droptol after a few dozen), and a
+    // dependent load per position just to find a zero is ~0.7 us: 64 positions are looked at together, the nonzero
+    // ones are worked in order, and after each of them the rest of the chunk is read again (it may have been filled).
+    // What does not depend on the values -- list bounds and pivot of every position of the chunk, and the first 64
+    // entries of the NEXT nonzero position -- is fetched ahead, so that a column costs the read-modify-write of its
+    // targets and the re-read of the chunk, not five more dependent loads.
     const int lane = lane_id();
     int nz = 0;
-    for (int n = 0; n < nz_symb; n++) {
-        const int ipivot = psym[n];
-        double x = lhs[ipivot];
-        if (x != 0.0) {
+    for (int n0 = 0; n0 < nz_symb; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < nz_symb;
+        const int ip = in ? psym[n] : 0;
+        double xl = in ? lhs[ip] : 0.0;
+        const int bl = in ? g.begin(ip) : 0, el = in ? g.end(ip) : 0;
+        const double pl = (PIV && in) ? g.pivot(ip) : 1.0;
+        unsigned long long todo = __ballot(xl != 0.0);
+        // entries of the first candidate
+        int cand = todo ? __ffsll((long long)todo) - 1 : -1;
+        int ci = -1;
+        double cv = 0.0;
+        if (cand >= 0) {
+            const int cb = wave_bcast_i(bl, cand), ce = wave_bcast_i(el, cand);
+            if (cb + lane < ce) {
+                ci = g.node(cb + lane);
+                cv = g.val(cb + lane);
+            }
+        }
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            const int ipivot = wave_bcast_i(ip, l);
+            const int b = wave_bcast_i(bl, l), e = wave_bcast_i(el, l);
+            double x = wave_bcast_d(xl, l);
+            // this column's first entries: prefetched if the guess was right
+            int i0 = ci;
+            double v0 = cv;
+            if (l != cand) {
+                i0 = -1;
+                v0 = 0.0;
+                if (b + lane < e) {
+                    i0 = g.node(b + lane);
+                    v0 = g.val(b + lane);
+                }
+            }
+            // guess the next position (the next one that is nonzero NOW) and fetch its first entries
+            const unsigned long long rest = todo & ~((2ull << l) - 1ull);
+            cand = (l < 63 && rest) ? __ffsll((long long)rest) - 1 : -1;
+            ci = -1;
+            cv = 0.0;
+            if (cand >= 0) {
+                const int cb = wave_bcast_i(bl, cand), ce = wave_bcast_i(el, cand);
+                if (cb + lane < ce) {
+                    ci = g.node(cb + lane);
+                    cv = g.val(cb + lane);
+                }
+            }
             if (PIV) {
-                x = x / g.pivot(ipivot);
+                x = x / wave_bcast_d(pl, l);
                 wave_mem_sync();
                 if (lane == 0) lhs[ipivot] = x;
                 flops++;
             }
-            const int b = g.begin(ipivot), e = g.end(ipivot);
-            for (int p = b + lane; p < e; p += 64) {
+            if (b + lane < e && i0 >= 0) lhs[i0] = __dsub_rn(lhs[i0], __dmul_rn(x, v0));
+            for (int p = b + 64 + lane; p < e; p += 64) {
                 const int i = g.node(p);
                 if (i >= 0) lhs[i] = __dsub_rn(lhs[i], __dmul_rn(x, g.val(p)));
             }
             if (G::FILTER) { // flop count = entries present
-                for (int p = b; p < e; p += 64) {
+                flops += __popcll(__ballot(b + lane < e && i0 >= 0));
+                for (int p = b + 64; p < e; p += 64) {
                     const int q = p + lane;
                     flops += __popcll(__ballot(q < e && g.node(q) >= 0));
                 }
@@ -272,6 +326,8 @@ __device__ __forceinline__ int solve_triangular(const G &g, int nz_symb, const i
                 lhs[ipivot] = 0.0;
             }
             wave_mem_sync();
+            xl = (in && lane > l) ? lhs[ip] : 0.0;
+            todo = __ballot(xl != 0.0);
         }
     }
     return nz;
@@ -324,10 +380,21 @@ __global__ void __launch_bounds__(64) k_solve_sparse(DevLU *Ds, FinishOut *Os, S
         // ---- transposed system (solve_sparse.rs:51-179): U', then L'
         const GraphW GW{D.qinv, D.ubeg, D.uidx, D.uval, (gcll)O.u_colptr, (gcd)O.u_value, rank};
         int M = marker + 1;
+#ifdef BLU_PROFILE
+        const long long tp0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         int top = solve_symbolic(GW, m, nrhs, irhs, W, M, &dfs_ring);
+#ifdef BLU_PROFILE
+        const long long tp1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         for (int n = lane; n < nrhs; n += 64) W.work[irhs[n]] = xrhs[n];
         wave_mem_sync();
         nz = solve_triangular<true>(GW, m - top, W.psym + top, droptol, W.work, W.pat, u_flops);
+#ifdef BLU_PROFILE
+        if (lane == 0)
+            printf("solve_sparse T, U' part: reach %d nodes in %.0f us (%.2f us each), numeric %d kept, %lld flops in %.0f us\n", m - top,
+                   (tp1 - tp0) / 2100.0, (tp1 - tp0) / 2100.0 / (m - top), nz, u_flops, ((long long)__builtin_amdgcn_s_memtime() - tp1) / 2100.0);
+#endif
         // permute into xlhs; the pattern goes from column to row indices (:95-106)
         M = marker + 2;
         for (int n = lane; n < nz; n += 64) {
