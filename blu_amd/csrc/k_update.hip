@@ -164,28 +164,58 @@ __global__ void __launch_bounds__(1024) k_upd_init(DevLU *Ds, FinishOut *Os, Upd
     }
 }
 
-// garbage_perm (garbage_perm.rs:16-48): keep the last occurrence of every column in the pivot sequence.  One lane.
-__device__ __forceinline__ void garbage_perm_lane0(const UpdWs &U, int m, int *marked, int M)
+// garbage_perm (garbage_perm.rs:16-48): keep the last occurrence of every column in the pivot sequence, order kept.
+// Whole wave, 64 positions at a time from the back: a position is kept if its column has not been seen further back
+// (marked) and no later position of the same chunk has it (the later one wins the atomicMax on lastpos[column]).
+// The compacted sequence grows downwards from `put`, which never reaches the positions still to be read.
+__device__ __forceinline__ void garbage_perm_wave(const UpdWs &U, int m, int *marked, int M, int *lastpos)
 {
     UpdState *st = U.st;
+    const int lane = lane_id();
     const int pivotlen = st->pivotlen;
     if (pivotlen <= m) return;
     int put = pivotlen;
-    for (int get = pivotlen - 1; get >= 0; get--) {
-        const int j = U.pvcol[get];
-        if (marked[j] != M) {
-            marked[j] = M;
-            put--;
-            U.pvcol[put] = j;
-            U.pvrow[put] = U.pvrow[get];
+    for (int hi = pivotlen - 1; hi >= 0; hi -= 64) {
+        const int get = hi - lane;
+        int j = 0, r = 0;
+        bool cand = false;
+        if (get >= 0) {
+            j = U.pvcol[get];
+            r = U.pvrow[get];
+            cand = marked[j] != M;
         }
+        if (cand) __hip_atomic_store(&lastpos[j], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_mem_sync();
+        if (cand) (void)__hip_atomic_fetch_max(&lastpos[j], get, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_mem_sync();
+        const bool keep = cand && __hip_atomic_load(&lastpos[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == get;
+        const unsigned long long kb = __ballot(keep);
+        if (keep) {
+            const int d = put - 1 - __popcll(kb & lanes_below(lane)); // lane 0 holds the latest position
+            U.pvcol[d] = j;
+            U.pvrow[d] = r;
+            marked[j] = M;
+        }
+        put -= __popcll(kb);
+        wave_mem_sync();
     }
-    UPD_CHECK(st, put + m == pivotlen);
-    for (int k = 0; k < m; k++) { // (ascending: source index >= destination index)
-        U.pvcol[k] = U.pvcol[put + k];
-        U.pvrow[k] = U.pvrow[put + k];
+    if (lane == 0) UPD_CHECK(st, put + m == pivotlen);
+    for (int k0 = 0; k0 < m; k0 += 64) { // (ascending: source index >= destination index; a chunk is read before it is written)
+        const int k = k0 + lane;
+        int c = 0, r = 0;
+        if (k < m) {
+            c = U.pvcol[put + k];
+            r = U.pvrow[put + k];
+        }
+        wave_mem_sync();
+        if (k < m) {
+            U.pvcol[k] = c;
+            U.pvrow[k] = r;
+        }
+        wave_mem_sync();
     }
-    st->pivotlen = m;
+    if (lane == 0) st->pivotlen = m;
+    wave_mem_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -610,6 +640,21 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
     // results of the serial part, handed to all lanes through LDS
     __shared__ int s_istri, s_nreach, s_havediag, s_top, s_rtop, s_stop, s_nzspike;
     __shared__ double s_newpiv, s_piverr, s_spike_diag;
+#ifdef BLU_PROFILE
+    const long long tu0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // the row eta into the marked work vector (update.rs:467-480) -- it can have tens of thousands of entries (the
+    // transposed solve through the U chain of a banded basis): every loop over it is spread over the lanes
+    {
+        const int rb = U.rbeg[nforrest], re = U.rbeg[nforrest + 1];
+        const int M = marker + 1;
+        for (int pos = rb + lane; pos < re; pos += 64) {
+            const int i = U.ridx[pos];
+            marked[i] = M;
+            U.work1[i] = U.rval[pos];
+        }
+        wave_mem_sync();
+    }
     if (lane == 0) {
         s_stop = 0;
         // ---- prepare: the diagonal entry of the spike moves to its end (update.rs:441-465)
@@ -631,14 +676,8 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
             U.ucval[put] = spike_diag;
         }
         const int nz_spike = put - sb; // without the diagonal
-        const int rb = U.rbeg[nforrest], re = U.rbeg[nforrest + 1];
         // ---- newpiv = spike_diag - dot(spike, row eta), intersection of the patterns counted (:467-513)
         const int M = marker + 1;
-        for (int pos = rb; pos < re; pos++) {
-            const int i = U.ridx[pos];
-            marked[i] = M;
-            U.work1[i] = U.rval[pos];
-        }
         double newpiv = spike_diag;
         int intersect = 0;
         for (int pos = sb; pos < sb + nz_spike; pos++) {
@@ -727,6 +766,9 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
     }
     wave_mem_sync();
     __syncthreads();
+#ifdef BLU_PROFILE
+    const long long tu1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (s_stop) return;
     const double newpiv = s_newpiv;
     const int nz_spike = s_nzspike;
@@ -736,20 +778,22 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
 
     // ---- test triangularity (:607-818)
     if (s_havediag) {
-        if (s_istri && lane == 0) { // symmetric permutation: reach = ipivot, then the pattern of the row eta (topological)
-            st->min_pivot = fmin(st->min_pivot, fabs(newpiv));
-            st->max_pivot = fmax(st->max_pivot, fabs(newpiv));
+        if (s_istri) { // symmetric permutation: reach = ipivot, then the pattern of the row eta (topological)
             const int nreach = nz_roweta + 1;
-            row_reach[0] = ipivot;
-            col_reach[0] = jpivot;
-            int pos = U.rbeg[nforrest];
-            for (int n = 1; n < nreach; n++) {
-                const int i = U.ridx[pos++];
+            const int rb = U.rbeg[nforrest];
+            for (int n = 1 + lane; n < nreach; n += 64) {
+                const int i = U.ridx[rb + n - 1];
                 row_reach[n] = i;
                 col_reach[n] = U.qmap[i];
             }
-            st->nsymperm_total += 1;
-            s_nreach = nreach;
+            if (lane == 0) {
+                st->min_pivot = fmin(st->min_pivot, fabs(newpiv));
+                st->max_pivot = fmax(st->max_pivot, fabs(newpiv));
+                row_reach[0] = ipivot;
+                col_reach[0] = jpivot;
+                st->nsymperm_total += 1;
+                s_nreach = nreach;
+            }
         }
     } else {
         // spike with a zero diagonal: augmenting path jpivot -> ... -> jpivot in the row-file graph (part 1)
@@ -810,15 +854,16 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
     }
     wave_mem_sync();
     __syncthreads();
+#ifdef BLU_PROFILE
+    const long long tu2 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const bool istriangular = s_istri != 0;
     if (istriangular && !s_havediag) reach_off = s_rtop;
 
-    if (lane == 0) {
-        int nreach = s_nreach;
-        int one_row = ipivot, one_col = jpivot;
-        const int *rr = row_reach + reach_off, *cr = col_reach + reach_off;
-        if (!istriangular) {
-            // ---- Forrest-Tomlin update (:820-889): row ipivot leaves U, the row eta takes its place
+    int nreach = s_nreach;
+    if (!istriangular) {
+        // ---- Forrest-Tomlin update (:820-889): row ipivot leaves U, the row eta takes its place
+        if (lane == 0) {
             int u_nz = st->u_nz;
             const int wb = U.wbeg[jpivot], we = wb + U.wlen[jpivot];
             for (int pos = wb; pos < we; pos++) { // remove row ipivot from the column file
@@ -842,43 +887,71 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
             U.row_pivot[ipivot] = newpiv;
             st->min_pivot = fmin(st->min_pivot, fabs(newpiv));
             st->max_pivot = fmax(st->max_pivot, fabs(newpiv));
-            // drop zeros from the row eta; largest eta entry
-            int nz = 0, put = U.rbeg[nforrest];
-            double max_eta = 0.0;
-            for (int pos = put; pos < U.rbeg[nforrest + 1]; pos++) {
-                const double x = U.rval[pos];
-                if (x != 0.0) {
-                    max_eta = fmax(max_eta, fabs(x));
-                    U.ridx[put] = U.ridx[pos];
-                    U.rval[put] = x;
-                    put++;
-                    nz++;
-                }
+        }
+        // drop zeros from the row eta (order kept); largest eta entry
+        int nz = 0;
+        const int rb0 = U.rbeg[nforrest], re0 = U.rbeg[nforrest + 1];
+        int put = rb0;
+        double max_eta = 0.0;
+        for (int c = rb0; c < re0; c += 64) {
+            const int pos = c + lane;
+            const double x = pos < re0 ? U.rval[pos] : 0.0;
+            const int ix = pos < re0 ? U.ridx[pos] : 0;
+            const unsigned long long kb = __ballot(x != 0.0);
+            wave_mem_sync();
+            if (x != 0.0) {
+                const int d = put + __popcll(kb & lanes_below(lane));
+                U.ridx[d] = ix;
+                U.rval[d] = x;
+                max_eta = fmax(max_eta, fabs(x));
             }
+            put += __popcll(kb);
+            nz += __popcll(kb);
+            wave_mem_sync();
+        }
+        max_eta = wave_max_d(max_eta);
+        if (lane == 0) {
             U.rbeg[nforrest + 1] = put;
             st->r_nz += nz;
             st->max_eta = fmax(st->max_eta, max_eta);
-            nreach = 1;
-            rr = &one_row;
-            cr = &one_col;
             st->nforrest = nforrest + 1;
             st->nforrest_total += 1;
         }
-        // ---- update permutations (:891-911)
-        if (st->pivotlen + nreach > 2 * m) garbage_perm_lane0(U, m, marked, marker + 3);
-        const int put = st->pivotlen;
-        for (int n = 0; n < nreach; n++) {
-            U.pvrow[put + n] = rr[n];
-            U.pvcol[put + n] = cr[n];
-        }
-        st->pivotlen = put + nreach;
-        // (the reference compresses the two files of U here when they have shrunk, update.rs:913-937: storage
-        // layout only; the device arenas are grown by the host on demand instead)
-        st->pivot_error = s_piverr / (1.0 + fabs(newpiv));
-        st->btran_for = -1;
-        st->ftran_for = -1;
-        st->update_cost_numer += (double)nz_roweta;
+        nreach = 1;
+        wave_mem_sync();
     }
+    // ---- update permutations (:891-911)
+    if (st->pivotlen + nreach > 2 * m) garbage_perm_wave(U, m, marked, marker + 3, W.estack);
+    {
+        const int put = st->pivotlen;
+        if (!istriangular) {
+            if (lane == 0) {
+                U.pvrow[put] = ipivot;
+                U.pvcol[put] = jpivot;
+            }
+        } else {
+            const int *rr = row_reach + reach_off, *cr = col_reach + reach_off;
+            for (int n = lane; n < nreach; n += 64) {
+                U.pvrow[put + n] = rr[n];
+                U.pvcol[put + n] = cr[n];
+            }
+        }
+        wave_mem_sync();
+        if (lane == 0) {
+            st->pivotlen = put + nreach;
+            // (the reference compresses the two files of U here when they have shrunk, update.rs:913-937: storage
+            // layout only; the device arenas are grown by the host on demand instead)
+            st->pivot_error = s_piverr / (1.0 + fabs(newpiv));
+            st->btran_for = -1;
+            st->ftran_for = -1;
+            st->update_cost_numer += (double)nz_roweta;
+        }
+    }
+#ifdef BLU_PROFILE
+    if (lane == 0)
+        printf("k_update: spike %d, row eta %d, havediag %d, triangular %d, nreach %d | spike+row file %.0f us | triangularity %.0f us | rest %.0f us\n", nz_spike,
+               nz_roweta, s_havediag, s_istri, s_nreach, (tu1 - tu0) / 2100.0, (tu2 - tu1) / 2100.0, ((long long)__builtin_amdgcn_s_memtime() - tu2) / 2100.0);
+#endif
     (void)nz_spike;
     (void)s_spike_diag;
 }
@@ -906,7 +979,7 @@ __global__ void __launch_bounds__(64) k_solve_dense_upd(DevLU *Ds, SparseWs W, U
     const int lane = lane_id();
     const int m = D.m;
     UpdState *st = U.st;
-    if (lane == 0) garbage_perm_lane0(U, m, W.marked, marker + 1); // solve_dense.rs:9
+    garbage_perm_wave(U, m, W.marked, marker + 1, W.estack); // solve_dense.rs:9
     wave_mem_sync();
     const int nforrest = st->nforrest;
     double *work1 = U.work1;
