@@ -94,6 +94,9 @@ enum blu_stat {
     BLU_STAT_DEV_TIME_PIVOT_LOOP = 40,  /* seconds, hipEvent, last factorize */
     BLU_STAT_DEV_TIME_TOTAL = 41,       /* seconds, hipEvent, all kernels of last factorize */
     BLU_STAT_DEV_RELAUNCHES = 42,       /* pivot-loop kernel launches of last factorize */
+    /* 44..47: device seconds of k_prep / k_setup / k_finish / the statistics tail of the last factorize;
+     * 108, 109: inside the statistics of a single factorize, k_rows_grid and k_stats_tail_a+b (diagnostic keys
+     * without enum names, as 50..58 and 60..107 of the diagnostic build) */
     BLU_STAT_NSYMPERM_TOTAL = 48,       /* lu.nsymperm_total: updates done by a symmetric permutation alone */
     BLU_STAT_NFORREST_TOTAL = 49,       /* lu.nforrest_total */
     BLU_STAT_DEV_NUNSYMPERM_TOTAL = 59, /* updates done by an unsymmetric permutation (update.rs:794-814); no getter in the reference */
