@@ -78,3 +78,25 @@ def test_update_fuzz_slice(seed, start, count):
         pytest.fail(_stop["why"] + "\n" + text[-2000:])
     assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
     assert ("all %d update cases of seed %d from %d identical" % (count, seed, start)) in text
+
+
+# ---- mid-size bases (m = 1500 .. 9000): the LDS rings of the chain pipeline wrap, operands come from beyond its window
+def test_fuzz_slice_mid_size():
+    if _stop["why"]:
+        pytest.skip("not started: " + _stop["why"])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzz_mid_s31.log")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--seed", "31", "--start", "0", "--count", "40", "--mmin", "1500",
+           "--mmax", "9000", "--log", log]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    except subprocess.TimeoutExpired:
+        _stop["why"] = "mid-size slice hung; last case started: %s" % _last_started(log)
+        pytest.fail(_stop["why"])
+    text = r.stdout.decode(errors="replace")
+    if r.returncode < 0 or r.returncode >= 124:
+        _stop["why"] = "mid-size slice was killed (rc %d); last case started: %s" % (r.returncode, _last_started(log))
+        pytest.fail(_stop["why"] + "\n" + text[-2000:])
+    assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
+    assert "all 40 cases of seed 31 from 0 identical" in text

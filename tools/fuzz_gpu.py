@@ -29,10 +29,13 @@ FSTATS = ("MIN_PIVOT", "MAX_PIVOT", "CONDEST_L", "CONDEST_U", "NORM_L", "NORM_U"
           "ONENORM", "INFNORM", "RESIDUAL_TEST")
 
 
+M_RANGE = [20, 700]  # --mmin / --mmax: larger bases (ring wraps and far operands of the chain pipeline, k_chain.h)
+
+
 def draw(rng):
     """The generator / LU parameters of one case (consumes the random stream exactly as round 1's tool did)."""
     c = {}
-    c["m"] = m = int(rng.integers(20, 700))
+    c["m"] = m = int(rng.integers(M_RANGE[0], M_RANGE[1]))
     c["k"] = int(rng.integers(2, 12))
     c["bw"] = int(rng.integers(1, 40))
     c["tri"] = float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0]))
@@ -122,7 +125,10 @@ def main():
     ap.add_argument("--start", type=int, default=0)
     ap.add_argument("--count", type=int, default=200)
     ap.add_argument("--log", default="")
+    ap.add_argument("--mmin", type=int, default=20)
+    ap.add_argument("--mmax", type=int, default=700)
     a = ap.parse_args()
+    M_RANGE[0], M_RANGE[1] = a.mmin, a.mmax
     log = open(a.log, "w") if a.log else sys.stdout
     rng = np.random.default_rng(a.seed)
     blu_amd = None
