@@ -1058,6 +1058,101 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, Mc *mc, int q, 
     }
 }
 
+// fast_col for a column of at most 64 entries (all but a handful): one chunk, no loops, the look-up of the common
+// case (first or second slot of the probe sequence) in straight-line code.  The line-update phase of a small pivot is
+// bound by the instruction throughput of the CU, so every instruction here is paid 20 times per
+// pivot.
+__device__ __forceinline__ int hrow_lookup2(const Fast *f, int k)
+{
+    const unsigned s0 = hslot(k, HROW_BITS), s1 = (s0 + 1) & (HROW - 1);
+    const unsigned long long x0 = f->hRow[s0], x1 = f->hRow[s1];
+    const bool h0 = (int)(x0 >> 32) == k, e0 = x0 == ~0ull, h1 = (int)(x1 >> 32) == k, e1 = x1 == ~0ull;
+    int r = h0 ? (int)(x0 & 0xffffffffull) : ((!e0 && h1) ? (int)(x1 & 0xffffffffull) : 0);
+    if (!(h0 || e0 || h1 || e1)) r = hrow_lookup(f, k); // a third probe: rare (tables at most a quarter full)
+    return r;
+}
+__device__ __forceinline__ void fast_col_short(const DevGP &D, Sm *sm, Mc *mc, int q, double *work, int idx, double val, int pr, int cnz1,
+                                               double pivot)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int j = fa->tJ[q], cb = fa->tB[q], cl = fa->tL[q], cap = fa->tC[q];
+    const bool v = lane < cl;
+    const int mk = v ? hrow_lookup2(fa, idx) : 0;
+    const bool keep = v && mk == 0;
+    if (v && mk > 0) work[mk - 1] = val;
+    const unsigned long long kb = __ballot(keep);
+    const int t = __popcll(kb & lanes_below(lane));
+    const unsigned long long pb = __ballot(keep && idx == pr);
+    DEV_CHECK(S, pb != 0ull);
+    const int psrc = pb ? __ffsll((long long)pb) - 1 : 0;
+    const int where = wave_bcast_i(t, psrc);
+    const double xrj = wave_bcast_d(val, psrc);
+    const int fsrc = kb ? __ffsll((long long)kb) - 1 : 0; // the first kept entry (t == 0)
+    const int first_idx = wave_bcast_i(idx, fsrc);
+    const double first_val = wave_bcast_d(val, fsrc);
+    double cmxl = (keep && lane != psrc) ? fabs(val) : 0.0;
+    const int nk1 = __popcll(kb) - 1;
+    const int need_max = nk1 + cnz1;
+    const bool reloc = need_max > cap;
+    int dst = cb, newcap = cap;
+    if (reloc) {
+        newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(&sm->cused, newcap);
+        dst = __builtin_amdgcn_readfirstlane(nb);
+    }
+    if (keep && t != where && t > 0) {
+        D.cidx[dst + t - 1] = idx;
+        D.cval[dst + t - 1] = val;
+    }
+    if (where > 0 && lane == 0) {
+        D.cidx[dst + where - 1] = first_idx;
+        D.cval[dst + where - 1] = first_val;
+    }
+    const double a = xrj / pivot;
+    const int put = dst + nk1;
+    const bool p = lane < cnz1;
+    double x = 0.0;
+    int ri = 0;
+    if (p) {
+        x = mulsub(work[lane], a, fa->pcV[1 + lane]);
+        ri = fa->pcI[1 + lane];
+        work[lane] = 0.0;
+    }
+    const double ax = fabs(x);
+    const bool kx = p && ax > D.droptol;
+    const unsigned long long kxb = __ballot(kx);
+    if (kx) {
+        const int d = __popcll(kxb & lanes_below(lane));
+        D.cidx[put + d] = ri;
+        D.cval[put + d] = x;
+        if (ax > cmxl) cmxl = ax;
+    }
+    const unsigned long long mask = __ballot(p && !kx);
+    const double cmx = wave_max_d(cmxl);
+    if (lane == 0) {
+        const int newlen = nk1 + __popcll(kxb);
+        D.cbeg[j] = dst;
+        D.clen[j] = newlen;
+        D.ccap[j] = newcap;
+        D.colmax[j] = cmx;
+        fa->tNew[q] = newlen;
+        if (q < 64) {
+            fa->tB[q] = dst;
+            fa->tMx[q] = cmx;
+            if (mc) mc->e1i[q] = -1;
+        }
+        fa->tX[q] = xrj;
+        fa->tM[q] = mask;
+        if (mask) fa->anycancel = 1;
+        if (reloc) atomicAdd((unsigned long long *)&sm->nexpand, 1ull);
+        if (mask >> 31) atomicAdd((unsigned long long *)&sm->d3, (unsigned long long)__popcll(mask >> 31));
+        if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
+    }
+}
+
 // kind 1: row p of the pivot column, ONE wave.  Appends the whole pivot-row pattern; positions
 // cancelled by fast_col are removed afterwards by fast_fixrow.
 __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, int j_first, int pc, int rnz1)
@@ -1109,6 +1204,50 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, 
             t0 += __popcll(kb);
         }
     }
+    for (int q = 1 + lane; q <= rnz1; q += 64) D.ridx[dst + nk + q - 1] = fa->tJ[q];
+    if (lane == 0) {
+        D.rbeg[i] = dst;
+        D.rlen[i] = nk + rnz1;
+        D.rcap[i] = newcap;
+        fa->rNew[p] = nk + rnz1;
+        fa->rKept[p] = nk;
+        fa->rDst[p] = dst;
+        if (reloc) atomicAdd((unsigned long long *)&sm->nexpand, 1ull);
+    }
+}
+
+// fast_row for a row of at most 64 entries: one chunk, straight-line
+__device__ __forceinline__ bool hcol_has2(const Fast *f, int k)
+{
+    const unsigned s0 = hslot(k, HCOL_BITS), s1 = (s0 + 1) & (HCOL - 1);
+    const unsigned long long x0 = f->hCol[s0], x1 = f->hCol[s1];
+    const bool h0 = (int)(x0 >> 32) == k, e0 = x0 == ~0ull, h1 = (int)(x1 >> 32) == k, e1 = x1 == ~0ull;
+    bool r = h0 || (!e0 && h1);
+    if (!(h0 || e0 || h1 || e1)) r = hcol_has(f, k);
+    return r;
+}
+__device__ __forceinline__ void fast_row_short(const DevGP &D, Sm *sm, Mc *mc, int p, int j, int pc, int rnz1)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int i = fa->pcI[p], rb = fa->prB[p], rl = fa->prL[p], cap = fa->prC[p];
+    const bool v = lane < rl;
+    const bool keep = v && !hcol_has2(fa, j);
+    DEV_CHECK(S, __ballot(v && j == pc) != 0ull);
+    const unsigned long long kb = __ballot(keep);
+    const int t0 = __popcll(kb & lanes_below(lane));
+    const int nk = __popcll(kb);
+    const int need_max = nk + rnz1;
+    const bool reloc = need_max > cap;
+    int dst = rb, newcap = cap;
+    if (reloc) {
+        newcap = need_max + stretch_of(D.stretch, need_max) + D.pad;
+        int nb = 0;
+        if (lane == 0) nb = atomicAdd(&sm->rused, newcap);
+        dst = __builtin_amdgcn_readfirstlane(nb);
+    }
+    if (keep) D.ridx[dst + t0] = j;
     for (int q = 1 + lane; q <= rnz1; q += 64) D.ridx[dst + nk + q - 1] = fa->tJ[q];
     if (lane == 0) {
         D.rbeg[i] = dst;
@@ -1367,8 +1506,13 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             const int t = tt[u];
-            if (t < rnz1) fast_col(D, sm, mc, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
-            else if (t < ntask) fast_row(D, sm, mc, t - rnz1 + 1, li[u], pc, rnz1);
+            if (t < rnz1) {
+                if (ll[u] <= 64) fast_col_short(D, sm, mc, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
+                else fast_col(D, sm, mc, t + 1, work, li[u], lv[u], pr, cnz1, pivot);
+            } else if (t < ntask) {
+                if (ll[u] <= 64) fast_row_short(D, sm, mc, t - rnz1 + 1, li[u], pc, rnz1);
+                else fast_row(D, sm, mc, t - rnz1 + 1, li[u], pc, rnz1);
+            }
 #ifdef BLU_PROFILE
             if (w == 1 && base == 0) PROF_STAMP_L0(35 + u);
 #endif
