@@ -210,6 +210,12 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ int num_waves() { return blockDim.x >> 6; }
 
 __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+// number of set bits of a ballot below THIS lane: v_mbcnt_lo / v_mbcnt_hi, two instructions (the shift-mask-popcount
+// form costs six; these sit in every compaction of the line updates, which are bound by instruction throughput)
+__device__ __forceinline__ int wave_prefix_count(unsigned long long b)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+}
 
 // Orders this wave's earlier global/LDS accesses before its later ones, for the lanes of THIS wave:
 // needed where one lane's store feeds another lane's later load.  A wave's memory instructions are

@@ -94,6 +94,7 @@ struct alignas(16) Sm {
     long long kinds[6];
     int sh[40];
     long long shl[20];
+    unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses
     double swork[16 * 64]; // one dense work column per wave; LAST member: the batch kernel allocates 4 of the 16
 };
 
@@ -456,7 +457,7 @@ __device__ __forceinline__ void gen_update_col(const DevGP &D, Sm *sm, int q, bo
         const bool keep = v && mk == 0;
         if (v && mk > 0) work[mk - 1] = val;
         const unsigned long long kb = __ballot(keep);
-        const int t = nkept + __popcll(kb & lanes_below(lane));
+        const int t = nkept + wave_prefix_count(kb);
         const bool ispr = keep && idx == pr;
         const unsigned long long pb = __ballot(ispr);
         if (pb) {
@@ -496,7 +497,7 @@ __device__ __forceinline__ void gen_update_col(const DevGP &D, Sm *sm, int q, bo
         const double val = v ? D.cval[cb + e] : 0.0;
         const bool keep = v && D.rowmark[idx] == 0;
         const unsigned long long kb = __ballot(keep);
-        const int t = __popcll(kb & lanes_below(lane));
+        const int t = wave_prefix_count(kb);
         if (keep && t != where && t > 0) {
             D.cidx[dst + t - 1] = idx;
             D.cval[dst + t - 1] = val;
@@ -510,7 +511,7 @@ __device__ __forceinline__ void gen_update_col(const DevGP &D, Sm *sm, int q, bo
             const double val = v ? D.cval[cb + e] : 0.0;
             const bool keep = v && D.rowmark[idx] == 0;
             const unsigned long long kb = __ballot(keep);
-            const int t = nk + __popcll(kb & lanes_below(lane));
+            const int t = nk + wave_prefix_count(kb);
             if (keep && t != where && t > 0) {
                 D.cidx[dst + t - 1] = idx;
                 D.cval[dst + t - 1] = val;
@@ -541,7 +542,7 @@ __device__ __forceinline__ void gen_update_col(const DevGP &D, Sm *sm, int q, bo
         const double ax = fabs(x);
         const bool kx = p && ax > D.droptol;
         const unsigned long long kb = __ballot(kx);
-        const int d = __popcll(kb & lanes_below(lane));
+        const int d = wave_prefix_count(kb);
         if (kx) {
             D.cidx[put + d] = ridx;
             D.cval[put + d] = x;
@@ -615,7 +616,7 @@ __device__ __forceinline__ void gen_update_row(const DevGP &D, Sm *sm, int p, bo
         const int j = v ? D.ridx[rb + e] : -1;
         const bool keep = v && D.colmark[j] == 0;
         const unsigned long long kb = __ballot(keep);
-        const int t = t0 + __popcll(kb & lanes_below(lane));
+        const int t = t0 + wave_prefix_count(kb);
         if (keep) D.ridx[dst + t] = j;
         t0 += __popcll(kb);
     }
@@ -629,7 +630,7 @@ __device__ __forceinline__ void gen_update_row(const DevGP &D, Sm *sm, int p, bo
         bool ok = v;
         if (small && v) ok = ((D.tmask[q] >> (p - 1)) & 1ull) == 0;
         const unsigned long long kb = __ballot(ok);
-        if (ok) D.ridx[put + na + __popcll(kb & lanes_below(lane))] = jq;
+        if (ok) D.ridx[put + na + wave_prefix_count(kb)] = jq;
         na += __popcll(kb);
     }
     if (lane == 0) {
@@ -654,7 +655,7 @@ __device__ __forceinline__ void wave_write_u(const DevGP &D, Sm *sm, int q0, int
         const bool k = v && fabs(x) > D.droptol;
         const unsigned long long kb = __ballot(k);
         if (k) {
-            const int d = put + __popcll(kb & lanes_below(lane));
+            const int d = put + wave_prefix_count(kb);
             D.uidx[d] = D.ridx[sm->prb + q];
             D.uval[d] = x;
         }
@@ -680,7 +681,7 @@ __device__ __forceinline__ void wave_write_l(const DevGP &D, Sm *sm, int p0, int
         const bool k = v && fabs(x) > D.droptol;
         const unsigned long long kb = __ballot(k);
         if (k) {
-            const int d = put + __popcll(kb & lanes_below(lane));
+            const int d = put + wave_prefix_count(kb);
             D.lidx[d] = D.cidx[sm->pcb + p];
             D.lval[d] = x;
         }
@@ -1100,7 +1101,7 @@ __device__ COLD bool pivot_doubleton_col(const DevGP &D, Sm *sm)
                 if (drop && j != pc) D.colmark[j] = 0;
                 const bool keep = v && !drop;
                 const unsigned long long kb = __ballot(keep);
-                if (keep) D.ridx[rb + t0 + __popcll(kb & lanes_below(lane))] = j;
+                if (keep) D.ridx[rb + t0 + wave_prefix_count(kb)] = j;
                 t0 += __popcll(kb);
             }
             DEV_CHECK(S, rl - t0 == ncancel + 1);
@@ -1136,7 +1137,7 @@ __device__ COLD bool pivot_doubleton_col(const DevGP &D, Sm *sm)
             const int q = 1 + c + lane;
             const bool ok = q <= rnz1 && (D.tmask[q] & 1ull);
             const unsigned long long kb = __ballot(ok);
-            if (ok) D.ridx[rb + rl + na + __popcll(kb & lanes_below(lane))] = D.ridx[prb + q];
+            if (ok) D.ridx[rb + rl + na + wave_prefix_count(kb)] = D.ridx[prb + q];
             na += __popcll(kb);
         }
         if (lane == 0) {
@@ -1237,6 +1238,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
 #endif
     }
     for (int k = tid; k < (int)blockDim.x; k += blockDim.x) sm->swork[k] = 0.0; // num_waves() x 64
+    if (tid < 16) sm->wmax[tid] = 0ull;
     for (int k = tid; k < 2 * KGMAX; k += blockDim.x) sm->fa.kg[0][k] = 0ull;
     if (tid == 0) {
         g_pivot_err = 0;

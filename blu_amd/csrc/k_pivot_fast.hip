@@ -950,7 +950,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, Mc *mc, int q, 
         const bool keep = v && mk == 0;
         if (v && mk > 0) work[mk - 1] = val;
         const unsigned long long kb = __ballot(keep);
-        const int t = nkept + __popcll(kb & lanes_below(lane));
+        const int t = nkept + wave_prefix_count(kb);
         const bool ispr = keep && idx == pr;
         const unsigned long long pb = __ballot(ispr);
         if (pb) {
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, Mc *mc, int q, 
             const double val = v ? D.cval[cb + e] : 0.0;
             const bool keep = v && hrow_lookup(fa, idx) == 0;
             const unsigned long long kb = __ballot(keep);
-            const int t = nk + __popcll(kb & lanes_below(lane));
+            const int t = nk + wave_prefix_count(kb);
             if (keep && t != where && t > 0) {
                 D.cidx[dst + t - 1] = idx;
                 D.cval[dst + t - 1] = val;
@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void fast_col(const DevGP &D, Sm *sm, Mc *mc, int q, 
     const bool kx = p && ax > D.droptol;
     const unsigned long long kb = __ballot(kx);
     if (kx) {
-        const int d = __popcll(kb & lanes_below(lane));
+        const int d = wave_prefix_count(kb);
         D.cidx[put + d] = ri;
         D.cval[put + d] = x;
         if (ax > cmxl) cmxl = ax;
@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void fast_col_short(const DevGP &D, Sm *sm, Mc *mc, i
     const bool keep = v && mk == 0;
     if (v && mk > 0) work[mk - 1] = val;
     const unsigned long long kb = __ballot(keep);
-    const int t = __popcll(kb & lanes_below(lane));
+    const int t = wave_prefix_count(kb);
     const unsigned long long pb = __ballot(keep && idx == pr);
     DEV_CHECK(S, pb != 0ull);
     const int psrc = pb ? __ffsll((long long)pb) - 1 : 0;
@@ -1125,14 +1125,20 @@ __device__ __forceinline__ void fast_col_short(const DevGP &D, Sm *sm, Mc *mc, i
     const bool kx = p && ax > D.droptol;
     const unsigned long long kxb = __ballot(kx);
     if (kx) {
-        const int d = __popcll(kxb & lanes_below(lane));
+        const int d = wave_prefix_count(kxb);
         D.cidx[put + d] = ri;
         D.cval[put + d] = x;
         if (ax > cmxl) cmxl = ax;
     }
     const unsigned long long mask = __ballot(p && !kx);
-    const double cmx = wave_max_d(cmxl);
+    // column maximum: one LDS atomic per lane with a candidate (non-negative doubles order like their bit patterns)
+    // instead of a 64-bit cross-lane reduction (~30 vector instructions); only lane 0 needs the result
+    unsigned long long *wm = &sm->wmax[wave_id()];
+    if (cmxl > 0.0) atomicMax(wm, (unsigned long long)__double_as_longlong(cmxl));
+    wave_mem_sync();
     if (lane == 0) {
+        const double cmx = __longlong_as_double((long long)*wm);
+        *wm = 0ull;
         const int newlen = nk1 + __popcll(kxb);
         D.cbeg[j] = dst;
         D.clen[j] = newlen;
@@ -1176,7 +1182,7 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, 
         if (c == 0) {
             j0 = j;
             keep0 = keep;
-            t0r = __popcll(kb & lanes_below(lane));
+            t0r = wave_prefix_count(kb);
         }
         nk += __popcll(kb);
     }
@@ -1200,7 +1206,7 @@ __device__ __forceinline__ void fast_row(const DevGP &D, Sm *sm, Mc *mc, int p, 
             const int j = v ? D.ridx[rb + e] : -1;
             const bool keep = v && !hcol_has(fa, j);
             const unsigned long long kb = __ballot(keep);
-            if (keep) D.ridx[dst + t0 + __popcll(kb & lanes_below(lane))] = j;
+            if (keep) D.ridx[dst + t0 + wave_prefix_count(kb)] = j;
             t0 += __popcll(kb);
         }
     }
@@ -1236,7 +1242,7 @@ __device__ __forceinline__ void fast_row_short(const DevGP &D, Sm *sm, Mc *mc, i
     const bool keep = v && !hcol_has2(fa, j);
     DEV_CHECK(S, __ballot(v && j == pc) != 0ull);
     const unsigned long long kb = __ballot(keep);
-    const int t0 = __popcll(kb & lanes_below(lane));
+    const int t0 = wave_prefix_count(kb);
     const int nk = __popcll(kb);
     const int need_max = nk + rnz1;
     const bool reloc = need_max > cap;
@@ -1278,7 +1284,7 @@ __device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, Mc *mc, int 
         const int q = 1 + c + lane;
         const bool ok = q <= rnz1 && ((fa->tM[q] >> (p - 1)) & 1ull) == 0;
         const unsigned long long kb = __ballot(ok);
-        if (ok) D.ridx[dst + nk + na + __popcll(kb & lanes_below(lane))] = fa->tJ[q];
+        if (ok) D.ridx[dst + nk + na + wave_prefix_count(kb)] = fa->tJ[q];
         na += __popcll(kb);
     }
     if (lane == 0) {
@@ -1311,7 +1317,7 @@ __device__ __forceinline__ void fast_write_u(const DevGP &D, Sm *sm, int q0, int
         const bool k = v && fabs(x) > D.droptol;
         const unsigned long long kb = __ballot(k);
         if (k) {
-            const int d = put + __popcll(kb & lanes_below(lane));
+            const int d = put + wave_prefix_count(kb);
             D.uidx[d] = fa->tJ[q];
             D.uval[d] = x;
         }
@@ -1338,7 +1344,7 @@ __device__ __forceinline__ void fast_write_l(const DevGP &D, Sm *sm)
         const bool k = v && fabs(x) > D.droptol;
         const unsigned long long kb = __ballot(k);
         if (k) {
-            const int d = put + __popcll(kb & lanes_below(lane));
+            const int d = put + wave_prefix_count(kb);
             D.lidx[d] = fa->pcI[p];
             D.lval[d] = x;
         }

@@ -83,7 +83,7 @@ typedef GraphUc GraphWr; // row of U under pivot column j: column indices (same 
 __device__ __forceinline__ int wave_append(int *pattern, int nz, bool take, int i)
 {
     const unsigned long long b = __ballot(take);
-    if (take) pattern[nz + __popcll(b & lanes_below(lane_id()))] = i;
+    if (take) pattern[nz + wave_prefix_count(b)] = i;
     return nz + __popcll(b);
 }
 
@@ -191,7 +191,7 @@ __device__ __forceinline__ void garbage_perm_wave(const UpdWs &U, int m, int *ma
         const bool keep = cand && __hip_atomic_load(&lastpos[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == get;
         const unsigned long long kb = __ballot(keep);
         if (keep) {
-            const int d = put - 1 - __popcll(kb & lanes_below(lane)); // lane 0 holds the latest position
+            const int d = put - 1 - wave_prefix_count(kb); // lane 0 holds the latest position
             U.pvcol[d] = j;
             U.pvrow[d] = r;
             marked[j] = M;
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(64) k_update(DevLU *Ds, SparseWs W, UpdWs U, d
             const unsigned long long kb = __ballot(x != 0.0);
             wave_mem_sync();
             if (x != 0.0) {
-                const int d = put + __popcll(kb & lanes_below(lane));
+                const int d = put + wave_prefix_count(kb);
                 U.ridx[d] = ix;
                 U.rval[d] = x;
                 max_eta = fmax(max_eta, fabs(x));
