@@ -1607,6 +1607,42 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
             continue;
         }
         const int j = fa->tJ[q], cb = fa->tB[q], cl = fa->tL[q];
+        if (cl <= 64) { // (all but a handful) one chunk, straight-line; the maximum through an LDS atomic
+            const bool v = lane < cl;
+            const int idx = v ? D.cidx[cb + lane] : -1;
+            const double val = v ? D.cval[cb + lane] : 0.0;
+            const unsigned long long hb = __ballot(v && idx == pr);
+            DEV_CHECK(S, hb != 0ull);
+            const int src = hb ? __ffsll((long long)hb) - 1 : 0;
+            const double xrj = wave_bcast_d(val, src);
+            unsigned long long *wm = &sm->wmax[w];
+            if (v && lane != src) {
+                const double x = fabs(val);
+                if (x > 0.0) atomicMax(wm, (unsigned long long)__double_as_longlong(x));
+                if (mc && cl == 2 && q < MC_PREV) { // the one entry that stays: the next search finds it in LDS
+                    mc->e1i[q] = idx;
+                    mc->e1v[q] = val;
+                }
+            }
+            // last entry into the hole (pivot.rs:991-993): it is in lane cl - 1
+            const int last_i = wave_bcast_i(idx, cl - 1);
+            const double last_v = wave_bcast_d(val, cl - 1);
+            wave_mem_sync();
+            if (lane == 0 && hb) {
+                const double cmx = __longlong_as_double((long long)*wm);
+                *wm = 0ull;
+                D.cidx[cb + src] = last_i;
+                D.cval[cb + src] = last_v;
+                D.clen[j] = cl - 1;
+                D.colmax[j] = cmx;
+                fa->tNew[q] = cl - 1;
+                if (q < 64) fa->tMx[q] = cmx;
+                if (mc && cl != 2 && q < MC_PREV) mc->e1i[q] = -1;
+                fa->tX[q] = xrj;
+                if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
+            }
+            continue;
+        }
         int where = -1;
         double xrj = 0.0, cmxl = 0.0;
         for (int c = 0; c < cl; c += 64) {
