@@ -741,6 +741,76 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
     }
     if (kind == 0) return;
 
+    if (nzr <= 64 && nzc <= 64) {
+        // ---- the common shape in straight-line form: one chunk of the pivot row, one of the pivot column, the first
+        // hash probe without a loop.  (The searching wave is alone on the critical path: its time is its instruction
+        // count.)  Same steps, same order of the loads as below.
+        const int jq0 = lane < nzr ? D.ridx[prb + lane] : -1;
+        if (kind == 1) {
+            for (int s = lane; s < HROW; s += 64) fa->hRow[s] = ~0ull;
+        }
+        for (int s = lane; s < HCOL; s += 64) fa->hCol[s] = ~0ull;
+        const int coff = fa->cOff[csel];
+        int hr_idx0 = 0, hr_slot0 = 0, hr_len0 = 0;
+        if (lane < nzc) {
+            const int slot = (lane == where) ? 0 : (lane == 0 ? where : lane);
+            const int idx = fa->sI[coff + lane], rlv = fa->sL[coff + lane];
+            fa->pcI[slot] = idx;
+            fa->pcV[slot] = fa->sV[coff + lane];
+            fa->prB[slot] = fa->sB[coff + lane];
+            fa->prL[slot] = rlv;
+            fa->prC[slot] = fa->sC[coff + lane];
+            hr_slot0 = slot;
+            hr_idx0 = idx;
+            hr_len0 = rlv;
+        }
+        const unsigned long long hb = __ballot(jq0 == pc);
+        if (!hb) {
+            DEV_CHECK(S, false);
+            if (lane == 0) sm->pc = -1;
+            return;
+        }
+        const int wpos = __ffsll((long long)hb) - 1;
+        PROF_STAMP(12);
+        int tb = 0, tl = 0, tc = 0;
+        if (lane < nzr) {
+            tb = D.cbeg[jq0];
+            tl = D.clen[jq0];
+            tc = D.ccap[jq0];
+        }
+        int gc = 0, gr = 0;
+        if (kind == 1 && hr_slot0 >= 1) {
+            hrow_insert(fa, hr_idx0, hr_slot0);
+            const int n = hr_len0 + nzr - 1;
+            gr = n + stretch_of(D.stretch, n) + D.pad;
+        }
+        if (lane < nzr) {
+            const int slot = kind == 1 ? ((lane == wpos) ? 0 : (lane == 0 ? wpos : lane)) : lane;
+            fa->tJ[slot] = jq0;
+            fa->tB[slot] = tb;
+            fa->tL[slot] = tl;
+            fa->tC[slot] = tc;
+            hcol_insert(fa, jq0, slot);
+            if (kind == 1 && lane != wpos) {
+                const int n = tl + nzc - 1;
+                gc = n + stretch_of(D.stretch, n) + D.pad;
+            }
+        }
+        PROF_STAMP(13);
+        if (kind == 1) {
+            // (each estimate is below 2^31: at most 64 lines of < 2^22 entries here)
+            const long long both = wave_sum_ll(((long long)gc << 32) | (long long)(unsigned)gr);
+            if ((long long)sm->cused + (both >> 32) > (long long)D.carena_cap || (long long)sm->rused + (both & 0xffffffffLL) > (long long)D.rarena_cap)
+                kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
+        }
+        if (lane == 0) {
+            fa->kind = kind;
+            fa->where = wpos;
+        }
+        PROF_STAMP(14);
+        return;
+    }
+
     // Order of the steps below: every global load is issued as early as its address is known and the LDS work
     // that does not depend on it runs while it is in flight (pivot row || pivot column copy; column metadata ||
     // row hash).
