@@ -326,17 +326,34 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
             }
         };
         const int last = nsteps - 1;
+        // The records of a block are read once, 64 lanes at a time: lane t holds the record of step bs + t (lanes 32,
+        // 33 reach into the next block for the look-ahead) and a step takes its fields by v_readlane -- a handful of
+        // scalar moves instead of LDS reads, address arithmetic and a three-stage rotation of ten registers per step.
+        const auto rl_d = [](double x, int t) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(x), t), hi = __builtin_amdgcn_readlane(__double2hiint(x), t);
+            return __hiloint2double(hi, lo);
+        };
+        const auto read_ops = [&](int eb, int nf) {
+            ChOps E;
+            E.val = 0.0;
+            E.xv = 0.0;
+            E.sel = CH_SEL_FAR;
+            const int n = nf < 0 ? 0 : (nf & (CH_HAS - 1));
+            if (lane < n) {
+                const int r = (eb + lane) & (CH_CE - 1);
+                const ChOpsV v = L->ev[r];
+                E.val = v.val;
+                E.xv = v.xv;
+                E.sel = L->sel[r];
+            }
+            return E;
+        };
         wait_block(0);
-        wait_block(1);
-        ChRec R1 = ch_read_rec(L, 0);
-        ChOps E1 = ch_read_ops(L, R1);
-        double xw1 = E1.sel >= 0 ? L->xwin[E1.sel] : 0.0;
-        ChRec R2 = ch_read_rec(L, 1 < last ? 1 : last);
-        ChOps E2 = ch_read_ops(L, R2);
-        ChRec R3 = ch_read_rec(L, 2 < last ? 2 : last);
-        double vprev = 0.0;
+        ChRec BR;
+        ChOps E1, E2;
+        double xw1 = 0.0, vprev = 0.0;
         for (int b = 0; b < nblk && !L->abort; b++) {
-            // the look-ahead of this block's steps reaches three steps into the next block
+            // the look-ahead of this block's steps reaches two steps into the next block
 #ifdef BLU_PROFILE
             const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -344,17 +361,26 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
 #ifdef BLU_PROFILE
             t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
 #endif
-            const int s_end = (b + 1) * CH_SB < nsteps ? (b + 1) * CH_SB : nsteps;
-            for (int s = b * CH_SB; s < s_end; s++) {
-                // ahead: window operands of step s+1, entries of s+2, record of s+3
+            const int bs = b * CH_SB;
+            {
+                const int sl = bs + lane;
+                BR = ch_read_rec(L, sl < last ? sl : last);
+            }
+            if (b == 0) {
+                E1 = read_ops(__builtin_amdgcn_readlane(BR.eb, 0), __builtin_amdgcn_readlane(BR.n, 0));
+                xw1 = E1.sel >= 0 ? L->xwin[E1.sel] : 0.0;
+                E2 = read_ops(__builtin_amdgcn_readlane(BR.eb, 1), __builtin_amdgcn_readlane(BR.n, 1));
+            }
+            const int ns = (bs + CH_SB < nsteps ? CH_SB : nsteps - bs);
+            for (int t = 0; t < ns; t++) {
+                // ahead: window operands of step s+1, entries of s+2
                 const double xw2 = E2.sel >= 0 ? L->xwin[E2.sel] : 0.0;
-                const ChOps E3 = ch_read_ops(L, R3);
-                const ChRec R4 = ch_read_rec(L, s + 3 < last ? s + 3 : last);
-                // step s
-                const int nf = __builtin_amdgcn_readfirstlane(R1.n), k1 = __builtin_amdgcn_readfirstlane(R1.k),
-                          w1 = __builtin_amdgcn_readfirstlane(R1.w);
+                const ChOps E3 = read_ops(__builtin_amdgcn_readlane(BR.eb, t + 2), __builtin_amdgcn_readlane(BR.n, t + 2));
+                // step s = bs + t
+                const int nf = __builtin_amdgcn_readlane(BR.n, t), k1 = __builtin_amdgcn_readlane(BR.k, t), w1 = __builtin_amdgcn_readlane(BR.w, t);
+                const double own1 = rl_d(BR.own, t), diag1 = rl_d(BR.diag, t);
                 const int n1 = nf < 0 ? -1 : (nf & (CH_HAS - 1));
-                double acc = R1.init;
+                double acc = rl_d(BR.init, t);
                 if (n1 > 0) {
                     const double x = E1.sel == CH_SEL_PREV ? vprev : (E1.sel >= 0 ? xw1 : E1.xv);
                     acc = ch_accumulate<SUB>(acc, lane < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
@@ -370,20 +396,17 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
                         acc = ch_accumulate<SUB>(acc, lane < nn ? __dmul_rn(out[E.gidx], E.val) : 0.0, nn);
                     }
                 }
-                const double v = f(k1, nf != 0, acc, R1.own, R1.diag);
+                const double v = f(k1, nf != 0, acc, own1, diag1);
                 if (lane == 0) {
                     L->xwin[k1 & (CH_W - 1)] = v;
                     out[w1] = v;
                 }
                 vprev = v;
-                R1 = R2;
                 E1 = E2;
                 xw1 = xw2;
-                R2 = R3;
                 E2 = E3;
-                R3 = R4;
             }
-            // block finished: drain the stores, publish (R1 is the first step of the next block now)
+            // block finished: drain the stores, publish (lane 32 of the records = the first step of the next block)
 #ifdef BLU_PROFILE
             const long long td0 = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -392,8 +415,9 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
             t_drain += (long long)__builtin_amdgcn_s_memtime() - td0;
 #endif
             ch_lds_fence();
-            if (lane == 0 && s_end < nsteps) {
-                L->chain_eb = R1.eb;
+            const int eb_next = __builtin_amdgcn_readlane(BR.eb, CH_SB);
+            if (lane == 0 && bs + CH_SB < nsteps) {
+                L->chain_eb = eb_next;
                 L->chain_done = b + 1;
             }
         }
