@@ -1341,7 +1341,11 @@ __device__ __forceinline__ void fast_row_short(const DevGP &D, Sm *sm, Mc *mc, i
 // rows of up to 64 entries in two register chunks -- 18 pair tasks per small pivot instead of 35 line tasks.
 // Bit-identical (87 parity tests), and no faster: a pair costs 5 500 cycles against 3 500 for one line (the
 // half-wide selects, twice the LDS set-up per task, more spilled registers) and the task set-up doubles, so a
-// wave's share takes as long as before: C3 pivot loop 820 -> 842 ms, batch kernel 1.21 -> 1.18 s.  Not kept.)
+// wave's share takes as long as before: C3 pivot loop 820 -> 842 ms, batch kernel 1.21 -> 1.18 s.  Not kept.
+// Tried again after the straight-line forms below, for the rows only (the cheap kind: pattern, no values): 745 -> 764
+// ms, batch kernel 1.03 -> 1.10 s -- one row in eight has more than 32 entries and its pair falls back to two
+// single updates with loads that were not issued ahead, and the per-lane selects of the pair set-up cost what the
+// shared instruction stream saves.  Not kept.)
 // rewrite the appended part of row p without the cancelled positions (pivot.rs:752-758)
 __device__ __forceinline__ void fast_fixrow(const DevGP &D, Sm *sm, Mc *mc, int p)
 {
