@@ -10,14 +10,15 @@
 // Here the wave that walks the chain never loads from global memory.  The other waves of the workgroup
 // (helpers) stream the operands of the coming steps into LDS rings -- step records (length, pivot, own value,
 // output index) and entries (value, and WHERE the operand of the work vector is found) -- hundreds of steps
-// ahead of the chain wave; the chain wave reads LDS only, three steps deep in registers, and its step is the
-// arithmetic: products, the ordered sum in the reference's order, the step function (one f64 division), one
-// LDS and one global store.  Work-vector operands come from
+// ahead of the chain wave; the chain wave reads LDS only (the records of a block once, a step's fields by v_readlane;
+// the entries two steps ahead) and its step is the arithmetic: products, the ordered sum in the reference's order,
+// the step function (one f64 division), one LDS and one global store.  Work-vector operands come from
 //   * a window of the last CH_W results in LDS (xwin, written by the chain wave itself),
 //   * the previous step's result, forwarded in a register,
-//   * for producers further back than the window: the value gathered from global memory by the helper
-//     (final for at least CH_W - CH_CS steps when the helper reads it; the chain wave drains its stores
-//     before it publishes the progress the helper waits for).
+//   * for producers at least CH_FAR steps back: the value gathered from global memory by the helper (final by
+//     then: a helper stages a block only after the chain wave has published -- stores drained -- a progress
+//     that puts every such producer behind it).  The leading terms of a step that are of this kind are added by
+//     the helper itself, in the step's order and with the chain wave's roundings: the chain wave starts behind them.
 // Every sweep is in GATHER form: step k reads results of earlier steps only.  The reference's scatter-form
 // loops (x[i] -= t_k * a_ik over column k, k in sweep order) are run over the transposed storage -- row-wise L
 // ascending, U rows descending in the pivot order (k_rows_grid below) -- accumulating into the step's own
