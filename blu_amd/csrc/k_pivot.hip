@@ -1232,6 +1232,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
         sm->stop_at = stop_at;
         sm->fa.kind = 0;
         sm->fa.ewValid = 0;
+        sm->fa.spOk = 0;
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
 #ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) sm->prof[k] = 0;
@@ -1359,11 +1360,11 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
                 sm->prof[38] += g_pstamp[37] - g_pstamp[36]; // third task done
                 sm->prof[39] += g_pstamp[38] - g_pstamp[37]; // all of wave 1's tasks done, stores drained
                 sm->prof[40] += g_pstamp[3] - g_pstamp[38];  // ... until every wave is past the barrier
-                if (g_pstamp[44] > g_pstamp[3]) { // early search of the next pivot, relative to stamp 3
-                    sm->prof[41] += g_pstamp[41] - g_pstamp[3];  // entered (preconditions, min of the new counts)
-                    sm->prof[42] += g_pstamp[42] - g_pstamp[41]; // waited for the list wave's pairs
-                    sm->prof[43] += g_pstamp[43] - g_pstamp[42]; // walk
-                    sm->prof[44] += g_pstamp[44] - g_pstamp[43]; // staging (or the express loads)
+                if (g_pstamp[44] > g_pstamp[1]) { // speculative search of the next pivot on the unlink wave, relative to stamp 1
+                    sm->prof[41] += g_pstamp[41] - g_pstamp[1];  // columns of the pivot row unlinked
+                    sm->prof[42] += g_pstamp[42] - g_pstamp[41]; // walk
+                    sm->prof[43] += g_pstamp[43] - g_pstamp[42]; // staging
+                    sm->prof[44] += g_pstamp[44] - g_pstamp[43]; // reduction, result published
                     sm->prof[45] += 1;
                 }
             }

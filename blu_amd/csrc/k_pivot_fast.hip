@@ -220,8 +220,11 @@ struct InHRow {
 //                         tail-append.  Returns the smallest key > 0.
 // skip = index in elems of an element that is not moved (the pivot column inside a singleton-column
 // pivot row, which is `gone`), or -1.
+// sfl/sbl (optional): the links of the elements as staged in LDS by the pivot set-up, indexed like elems (the
+// element that is only removed: index gone_at)
 template <class Links, class InSet>
-__device__ __forceinline__ void wave_list_unlink_set(const Links &L, const int *elems, int n, int skip, InSet inS, int gone)
+__device__ __forceinline__ void wave_list_unlink_set(const Links &L, const int *elems, int n, int skip, InSet inS, int gone,
+                                                     const int *sfl = nullptr, const int *sbl = nullptr, int gone_at = 0)
 {
     const int lane = lane_id();
     const bool mov = lane < n && lane != skip;
@@ -229,8 +232,14 @@ __device__ __forceinline__ void wave_list_unlink_set(const Links &L, const int *
     const int e = mov ? elems[lane] : (unl ? gone : 0);
     int p = 0, nx = 0;
     if (unl) {
-        p = L.bl(e);
-        nx = L.fl(e);
+        if (sfl) {
+            const int at = mov ? lane : gone_at;
+            p = sbl[at];
+            nx = sfl[at];
+        } else {
+            p = L.bl(e);
+            nx = L.fl(e);
+        }
     }
     int sl, pl, dummy;
     inS.lanes_of(nx, p, 0, unl, unl, false, n, sl, pl, dummy);
@@ -685,7 +694,8 @@ __device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, Mc *mc, int &
 }
 
 // single: one candidate entry (a column singleton): nothing to reduce
-__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long long mcb, int fb, int nsearched, bool single)
+// key_given >= 0: the reduction was done already (spec_finish)
+__device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long long mcb, int fb, int nsearched, bool single, long long key_given = -1)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -696,7 +706,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
     const long long BIG = 0x7fffffffffffffffLL;
     if (lane == 0) fa->kind = 0;
     // key = cost * 256 + position (position < STGMAX <= 256, cost < 2^55); first-seen entry wins ties
-    const long long bestkey = single ? 0LL : wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
+    const long long bestkey = key_given >= 0 ? key_given : (single ? 0LL : wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG));
     wave_mem_sync();
     if (bestkey == BIG) { // no eligible entry: cannot happen when colmax is the column maximum
         DEV_CHECK(S, false);
@@ -772,11 +782,13 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
         }
         const int wpos = __ffsll((long long)hb) - 1;
         PROF_STAMP(12);
-        int tb = 0, tl = 0, tc = 0;
+        int tb = 0, tl = 0, tc = 0, tfl = 0, tbl = 0;
         if (lane < nzr) {
             tb = D.cbeg[jq0];
             tl = D.clen[jq0];
             tc = D.ccap[jq0];
+            tfl = D.cflink[jq0]; // for the unlink wave: same round trip, one less on its own chain
+            tbl = D.cblink[jq0];
         }
         int gc = 0, gr = 0;
         if (kind == 1 && hr_slot0 >= 1) {
@@ -790,6 +802,9 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
             fa->tB[slot] = tb;
             fa->tL[slot] = tl;
             fa->tC[slot] = tc;
+            fa->tFl[slot] = tfl;
+            fa->tBl[slot] = tbl;
+            fa->tNew[slot] = 0x7fffffff; // "not updated yet" (spec_walk looks at the new counts as they come in)
             hcol_insert(fa, jq0, slot);
             if (kind == 1 && lane != wpos) {
                 const int n = tl + nzc - 1;
@@ -806,6 +821,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
         if (lane == 0) {
             fa->kind = kind;
             fa->where = wpos;
+            fa->tLnk = 1;
         }
         PROF_STAMP(14);
         return;
@@ -918,6 +934,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
     if (lane == 0) {
         fa->kind = kind;
         fa->where = wpos;
+        fa->tLnk = 0;
     }
     PROF_STAMP(14);
 }
@@ -933,6 +950,8 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
     int nsr = 0;
     if (BLU_EARLY && !BATCH && fa->ewValid) { // found and staged while the previous pivot was being finished (early_search)
         const int lane = lane_id();
+        const bool whole = fa->ewValid == 2; // a whole search (spec_walk + spec_finish): the winner's key is in spKey
+        const long long key = whole ? fa->spKey : -1;
         const long long mcb = ew_mcb;
         const int fb = ew_fb;
         nsr = fa->ewNsr;
@@ -942,11 +961,23 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
         { // self-checking build: the ordinary search must give the same candidates, costs and count
             const int sN = fa->ncand;
             const int myc = lane < sN ? fa->cJ[lane] : -1;
+            // (whole search: every staged entry with its row's begin, length and capacity as well)
+            const int sT = whole ? fa->cOff[sN] : 0;
+            int kI[2], kB[2], kL[2], kC[2];
+            double kV[2];
+            for (int u = 0; u < 2; u++) {
+                const int f = lane + 64 * u;
+                kI[u] = f < sT ? fa->sI[f] : 0;
+                kB[u] = f < sT ? fa->sB[f] : 0;
+                kL[u] = f < sT ? fa->sL[f] : 0;
+                kC[u] = f < sT ? fa->sC[f] : 0;
+                kV[u] = f < sT ? fa->sV[f] : 0.0;
+            }
             wave_mem_sync();
             int nsr2 = 0, fb2 = 0;
             long long mcb2 = 0;
             bool okc = true;
-            if (!mk_express(D, sm, mc, nsr2)) {
+            if (whole || !mk_express(D, sm, mc, nsr2)) {
                 const int r2 = mk_walk(D, sm, mc);
                 if (r2 == 0) {
                     mk_stage(D, sm, mc, mcb2, fb2);
@@ -954,6 +985,17 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
                 } else {
                     okc = false;
                 }
+            }
+            if (whole) {
+                const long long BIGK = 0x7fffffffffffffffLL;
+                const long long key2 = wave_min_ll(mcb2 != BIGK ? mcb2 * 256LL + (long long)fb2 : BIGK);
+                okc = okc && key2 == key && fa->cOff[fa->ncand] == sT;
+                for (int u = 0; u < 2; u++) {
+                    const int f = lane + 64 * u;
+                    if (okc && f < sT) okc = fa->sI[f] == kI[u] && fa->sB[f] == kB[u] && fa->sL[f] == kL[u] && fa->sC[f] == kC[u] && fa->sV[f] == kV[u];
+                }
+                mcb2 = mcb;
+                fb2 = fb;
             }
             okc = okc && fa->ncand == sN && nsr2 == nsr && mcb2 == mcb && fb2 == fb && (lane >= sN || fa->cJ[lane] == myc);
             if (__ballot(!okc)) {
@@ -971,7 +1013,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
 #endif
         PROF_STAMP(9);
         PROF_STAMP(10);
-        mk_pick(D, sm, mc, mcb, fb, nsr, true);
+        mk_pick(D, sm, mc, mcb, fb, nsr, true, key);
         return true;
     }
     if (mk_express(D, sm, mc, nsr)) {
@@ -1510,9 +1552,169 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, con
             return;
         }
     }
-    // No singleton: the full walk (3 dependent candidate loads, then the staging) takes ~8 000 cycles here
-    // against ~5 500 in the ordinary search and the 2 000 of the finalize step it would hide behind:
-    // measured as a net loss, so that case is left to the ordinary search.
+    // No singleton: a full walk HERE (3 dependent candidate loads, then the staging) takes ~8 000 cycles
+    // against ~5 500 in the ordinary search and the 2 000 of the finalize step it would hide behind: measured
+    // as a net loss.  The walk that pays is the one that starts beside the line updates (spec_walk below).
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speculative search: the search of pivot k+1 beside the line updates of pivot k (kind 1), on the wave that has
+// just unlinked the columns of the pivot row from their count lists and would otherwise wait for the barrier.
+//   spec_walk    (beside the line updates) the list walk of the next search on the list state WITHOUT the columns
+//                being updated: the first K unmoved columns in list order with their (begin, len, max).  Four
+//                dependent round trips -- the long pole of the search -- off the critical path.
+//   spec_cond    (after the barrier) the walk is the next search's own walk if no moved column comes before the
+//                K-th candidate in the updated lists.  Moved columns are appended at the TAILS of their new lists,
+//                so it is enough that none has a new count below that of the last candidate; and K candidates were
+//                found (fewer: the moved columns would fill up), nothing cancelled, no column fell below abstol, no
+//                empty column.  The walk already watches the new counts as the line updates deliver them and gives
+//                up at the first one that is too small.
+//   spec_finish  (finalize step, same wave) entries, row metadata, costs, winner: what mk_stage and the reduction
+//                of mk_pick would do, on data that is final by then.
+// On the banded C3 basis the condition holds after 48 % of the kind-1 pivots (24 079 of 49 927); for them the next
+// search is a key picked up from LDS: pivot loop 748 -> 698 ms.  The wave runs at raised priority (s_setprio): its
+// chain of loads is the longest thing in the phase and it issues few instructions (715 against 742 ms without).
+// Nothing here is read by the current pivot: the candidate and staging arrays were consumed by its own set-up.
+// `make ewcheck` compares every such result -- candidates, count, key and every staged entry -- with the ordinary
+// search.  Built and measured on the way, not kept: reuse of the current search's surviving candidates and their
+// staged entries instead of walking them again (never more than two of four survive and the bookkeeping costs more
+// instructions on a contended SIMD than the two round trips it saves: 715 -> 767 ms).
+// ------------------------------------------------------------------------------------------------
+#ifdef BLU_SPEC_STATS
+#define SPEC_STAT(i) do { if (lane_id() == 0) atomicAdd((unsigned long long *)&D.s->prof[40 + (i)], 1ull); } while (0)
+#else
+#define SPEC_STAT(i) do { } while (0)
+#endif
+__device__ __forceinline__ void spec_walk(const DevGP &D, Sm *sm, Mc *mc)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (lane == 0) fa->spOk = 0;
+    if (!mc || D.no_fast || K < 1 || K > KCMAX || m >= (1 << 27)) return;
+    if (m - (sm->rank + 1) - sm->rankdef < K) return;
+    const LinksC LC{D, mc};
+    if (LC.fl(m) != m) return;
+    SPEC_STAT(0);
+    PROF_STAMP_L0(41);
+    // The line updates run beside this: a column that is done has its new count in tNew (set to "not yet" by the
+    // set-up).  One below the count of a candidate already decides that this search will not be the next one
+    // (spec_cond): stop at once and leave the SIMD to the updates.
+    const int nq = fa->tLnk ? sm->nzr - 1 : 0;
+    int ncand = 0, total = 0, lastnz = 0;
+    int nz = sm->min_colnz; // (the current search's: a lower bound of every unmoved column's count)
+    bool bad = false;
+    while (ncand < K && nz <= m && !bad) {
+        const int k = nz + lane;
+        const int h = k <= m ? LC.fl(m + k) : m + k;
+        unsigned long long ne = __ballot(k <= m && h != m + k);
+        while (ne && ncand < K && !bad) {
+            const int b = __ffsll((long long)ne) - 1;
+            ne &= ne - 1;
+            int j = wave_bcast_i(h, b);
+            const int znz = nz + b;
+            int guard = 0;
+            while (j < m && ncand < K) {
+                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
+                const double cmx = D.colmax[j];
+                const int kq = lane < nq ? fa->tNew[1 + lane] : 0x7fffffff;
+                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2 || __ballot(kq < znz)) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = znz;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = cl;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                total += cl;
+                ncand++;
+                lastnz = znz;
+                j = fl;
+            }
+        }
+        nz += 64;
+    }
+    if (bad || ncand < K || total > STGMAX) return;
+    SPEC_STAT(1);
+    if (lane == 0) {
+        fa->cOff[ncand] = total;
+        fa->ncand = ncand;
+        fa->spLastNz = lastnz;
+        fa->spOk = 1;
+    }
+    wave_mem_sync();
+    PROF_STAMP_L0(42);
+}
+
+// After the barrier that ends the line updates: can the walk above still become the next search?  Evaluated by the
+// wave that walked (it goes on to stage the entries, spec_finish) and by wave 0 (it looks for a column singleton
+// instead if not, early_search): the same LDS words, the same answer.  keys = new counts of the n moved columns.
+__device__ __forceinline__ bool spec_cond(const Sm *sm, const int *keys, int n)
+{
+    const int lane = lane_id();
+    const Fast *fa = &sm->fa;
+    if (!fa->spOk || sm->flag_small || fa->anycancel || n >= 64) return false;
+    const int kq = lane < n ? keys[lane] : 0x7fffffff;
+    return __ballot(kq < fa->spLastNz) == 0ull;
+}
+
+// The second half, in the finalize step (this wave has no other job there): the candidates' entries and the
+// metadata of their rows -- final now, also for the rows this pivot rewrote: the barrier has drained the stores of
+// the line updates -- the cost of every eligible entry, the winner.  Publishes the result for the next search
+// (ewValid = 2).  (Staging before the barrier and only the costs here was measured too: the barrier comes later
+// by more than this step gets shorter, 699 -> 707 ms.)
+__device__ __forceinline__ void spec_finish(const DevGP &D, Sm *sm)
+{
+    const int lane = lane_id();
+    Fast *fa = &sm->fa;
+    const int ncand = fa->ncand, total = fa->cOff[ncand];
+    const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
+              off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
+    const long long BIG = 0x7fffffffffffffffLL;
+    long long mcb = BIG;
+    int fb = 0x7fffffff;
+    for (int base = 0; base < total; base += 64) {
+        const int f = base + lane;
+        if (f < total) {
+            const int c = (f >= off1) + (f >= off2) + (f >= off3);
+            const int pos = fa->cB[c] + (f - fa->cOff[c]);
+            const int idx = D.cidx[pos];
+            const double val = D.cval[pos];
+            const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+            fa->sI[f] = idx;
+            fa->sV[f] = val;
+            fa->sB[f] = rb;
+            fa->sL[f] = rl;
+            fa->sC[f] = rc;
+            const double tol = fmax(D.abstol, D.reltol * fa->cMx[c]);
+            const double x = fabs(val);
+            if (!(x == 0.0 || x < tol)) {
+                const long long cost = (long long)(fa->cNz[c] - 1) * (long long)(rl - 1);
+                if (cost < mcb) {
+                    mcb = cost;
+                    fb = f;
+                }
+            }
+        }
+    }
+    PROF_WAIT();
+    PROF_STAMP_L0(43);
+    SPEC_STAT(2);
+    const long long key = wave_min_ll(mcb != BIG ? mcb * 256LL + (long long)fb : BIG);
+    if (key == BIG) return;
+    SPEC_STAT(3);
+    if (lane == 0) {
+        fa->spKey = key;
+        fa->ewNsr = ncand;
+        fa->ewValid = 2;
+    }
+    wave_mem_sync();
+    PROF_STAMP_L0(44);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1542,7 +1744,19 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
     const bool split = !BATCH && nw >= 8 && rnz1 < 64;
     const int nwt = split ? nw - 1 : nw;
     const LinksC LC{D, mc};
-    if (split && w == nw - 1) wave_list_unlink_set(LC, fa->tJ + 1, rnz1, -1, InHCol{fa, 1, 0}, pc);
+    const bool early = BLU_EARLY && split && !D.search_rows;
+    if (split && w == nw - 1) {
+        // this wave's chain of dependent loads is the longest thing in the phase and it issues few instructions:
+        // it goes first on its SIMD
+        if (early && BLU_SPEC) __builtin_amdgcn_s_setprio(3);
+        const bool lnk = fa->tLnk != 0; // (elems = tJ + 1: staged links from slot 1, the pivot column's at slot 0 = index -1)
+        wave_list_unlink_set(LC, fa->tJ + 1, rnz1, -1, InHCol{fa, 1, 0}, pc, lnk ? fa->tFl + 1 : nullptr, lnk ? fa->tBl + 1 : nullptr, -1);
+        if (early && BLU_SPEC) {
+            wave_mem_sync();
+            spec_walk(D, sm, mc);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
     for (int base = 0; base < ntask && w < nwt; base += 3 * nwt) {
         int li[3], tt[3];
         double lv[3];
@@ -1614,8 +1828,9 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
     // finalize step, one job per wave: [0] the search of the NEXT pivot (early_search), [1] L column,
     // [2] count lists, [3] U row and the pivot's own bookkeeping; with fewer than 4 waves (or row search)
     // wave 0 writes the U row instead and the next search waits for the barrier
-    const bool early = BLU_EARLY && split && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
+    const bool spec = BLU_SPEC && early && (w == 0 || w == nw - 1) && spec_cond(sm, fa->tNew + 1, rnz1);
+    if (w == 0 && early && !spec) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
+    if (w == nw - 1 && spec) spec_finish(D, sm);
     if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
         if (lane == 0) {
@@ -1674,7 +1889,10 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
     const bool split = !BATCH && nw >= 8 && rl < 64;
     const int nwt = split ? nw - 1 : nw;
     const LinksC LC{D, mc};
-    if (split && w == nw - 1) wave_list_unlink_set(LC, fa->tJ, rl, wq, InHCol{fa, 0, wq}, pc);
+    if (split && w == nw - 1) {
+        const bool lnk = fa->tLnk != 0;
+        wave_list_unlink_set(LC, fa->tJ, rl, wq, InHCol{fa, 0, wq}, pc, lnk ? fa->tFl : nullptr, lnk ? fa->tBl : nullptr, wq);
+    }
     for (int q = w; q < rl && w < nwt; q += nwt) {
         if (q == wq) {
             if (lane == 0) fa->tNew[q] = -1;

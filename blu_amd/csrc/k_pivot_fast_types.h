@@ -38,6 +38,11 @@
 #ifndef BLU_EARLY
 #define BLU_EARLY 1
 #endif
+// Speculative search (spec_walk / spec_finish in k_pivot_fast.hip): the search of the next pivot beside the line
+// updates and the finalize step of a kind-1 pivot.  -DBLU_SPEC=0 switches it off.
+#ifndef BLU_SPEC
+#define BLU_SPEC 1
+#endif
 
 // ---- list heads of the single-matrix kernel in LDS (k_pivot_loop; the batch kernel has none) ---------------
 // Heads and tails of the column count lists 0..MC_HEADS-1 (cflink/cblink[m + k]) live in LDS: every search
@@ -73,13 +78,16 @@ struct Fast {
     double cMx[KCMAX];
     // early search: hand-over from the list wave (unlinked runs: predecessor -> first unmoved successor)
     // and the result kept for the next search
-    int ewValid, ewNsr;
+    int ewValid, ewNsr; // ewValid: 1 = a column singleton (early_search), 2 = a whole search (spec_finish), key in spKey
+    int spOk, spLastNz; // speculative search of the next pivot: walk complete / count of its last candidate
+    long long spKey;    // its winner: cost * 256 + flat position
     double tMx[64]; // new maximum of the first 64 columns of the pivot row (the next search reuses rows < 64 only)
     // pivot column, pivot at slot 0 (kind 1), with the (begin,len,cap) of each row
     int pcI[PCMAX], prB[PCMAX], prL[PCMAX], prC[PCMAX], rNew[PCMAX], rKept[PCMAX], rDst[PCMAX];
     double pcV[PCMAX];
     // pivot row, pivot column at slot 0 (kind 1), with the (begin,len,cap) of each column
     int tJ[PRMAX], tB[PRMAX], tL[PRMAX], tC[PRMAX], tNew[PRMAX];
+    int tFl[64], tBl[64], tLnk; // tLnk: the count-list links of the row's columns (slots < 64) were loaded with their metadata
     double tX[PRMAX]; // pivot-row value of the column
     unsigned long long tM[PRMAX];
     // staged candidate entries

@@ -38,5 +38,5 @@ print("fast small, finalize step (cycles after the barrier): U row written @%.0f
 print("fast small, line updates as wave 1 sees them: %.1f column + %.1f row tasks per pivot; cycles: loads issued %.0f | arrived %.0f | task 1 %.0f | task 2 %.0f | task 3 %.0f | rest + drain %.0f | waiting for the others %.0f"
       % (cyc(32), cyc(33), cyc(34), cyc(35), cyc(36), cyc(37), cyc(38), cyc(39), cyc(40)))
 ne = max(1, p[45])
-print("early search of the next pivot, after fast small pivots (%d of %d): enters @%.0f | waits for the pairs %.0f | walk %.0f | staging %.0f cycles"
+print("speculative search on the unlink wave, beside the line updates (%d of %d ran to the end): unlink done @%.0f | walk %.0f | staging %.0f | reduction %.0f cycles"
       % (p[45], n1, p[41] / ne, p[42] / ne, p[43] / ne, p[44] / ne))
