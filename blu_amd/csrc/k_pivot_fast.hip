@@ -787,8 +787,10 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
             tb = D.cbeg[jq0];
             tl = D.clen[jq0];
             tc = D.ccap[jq0];
+#if !BLU_CFG_BATCH
             tfl = D.cflink[jq0]; // for the unlink wave: same round trip, one less on its own chain
             tbl = D.cblink[jq0];
+#endif
         }
         int gc = 0, gr = 0;
         if (kind == 1 && hr_slot0 >= 1) {
@@ -802,9 +804,11 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
             fa->tB[slot] = tb;
             fa->tL[slot] = tl;
             fa->tC[slot] = tc;
+#if !BLU_CFG_BATCH // (the batch kernel has no unlink wave and no speculative search)
             fa->tFl[slot] = tfl;
             fa->tBl[slot] = tbl;
             fa->tNew[slot] = 0x7fffffff; // "not updated yet" (spec_walk looks at the new counts as they come in)
+#endif
             hcol_insert(fa, jq0, slot);
             if (kind == 1 && lane != wpos) {
                 const int n = tl + nzc - 1;
@@ -821,7 +825,7 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
         if (lane == 0) {
             fa->kind = kind;
             fa->where = wpos;
-            fa->tLnk = 1;
+            fa->tLnk = BLU_CFG_BATCH ? 0 : 1;
         }
         PROF_STAMP(14);
         return;

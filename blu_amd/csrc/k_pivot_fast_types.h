@@ -87,7 +87,11 @@ struct Fast {
     double pcV[PCMAX];
     // pivot row, pivot column at slot 0 (kind 1), with the (begin,len,cap) of each column
     int tJ[PRMAX], tB[PRMAX], tL[PRMAX], tC[PRMAX], tNew[PRMAX];
+#if BLU_CFG_BATCH
+    int tFl[1], tBl[1], tLnk; // (single-matrix kernel only)
+#else
     int tFl[64], tBl[64], tLnk; // tLnk: the count-list links of the row's columns (slots < 64) were loaded with their metadata
+#endif
     double tX[PRMAX]; // pivot-row value of the column
     unsigned long long tM[PRMAX];
     // staged candidate entries
