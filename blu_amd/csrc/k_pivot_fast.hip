@@ -807,7 +807,6 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
 #if !BLU_CFG_BATCH // (the batch kernel has no unlink wave and no speculative search)
             fa->tFl[slot] = tfl;
             fa->tBl[slot] = tbl;
-            fa->tNew[slot] = 0x7fffffff; // "not updated yet" (spec_walk looks at the new counts as they come in)
 #endif
             hcol_insert(fa, jq0, slot);
             if (kind == 1 && lane != wpos) {
@@ -1566,23 +1565,25 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, con
 // just unlinked the columns of the pivot row from their count lists and would otherwise wait for the barrier.
 //   spec_walk    (beside the line updates) the list walk of the next search on the list state WITHOUT the columns
 //                being updated: the first K unmoved columns in list order with their (begin, len, max).  Four
-//                dependent round trips -- the long pole of the search -- off the critical path.
-//   spec_cond    (after the barrier) the walk is the next search's own walk if no moved column comes before the
-//                K-th candidate in the updated lists.  Moved columns are appended at the TAILS of their new lists,
-//                so it is enough that none has a new count below that of the last candidate; and K candidates were
-//                found (fewer: the moved columns would fill up), nothing cancelled, no column fell below abstol, no
-//                empty column.  The walk already watches the new counts as the line updates deliver them and gives
-//                up at the first one that is too small.
-//   spec_finish  (finalize step, same wave) entries, row metadata, costs, winner: what mk_stage and the reduction
-//                of mk_pick would do, on data that is final by then.
-// On the banded C3 basis the condition holds after 48 % of the kind-1 pivots (24 079 of 49 927); for them the next
-// search is a key picked up from LDS: pivot loop 748 -> 698 ms.  The wave runs at raised priority (s_setprio): its
-// chain of loads is the longest thing in the phase and it issues few instructions (715 against 742 ms without).
+//                dependent round trips -- the long pole of a search -- off the critical path.
+//   spec_cond    (after the barrier) K unmoved candidates were found, nothing cancelled, no column fell below
+//                abstol, no column became empty.
+//   spec_finish  (finalize step, same wave) MERGE: the updated columns are appended at the TAILS of their new
+//                lists, in pivot-row order, so the candidates of the next search are the first K of [the walk's
+//                unmoved columns] merged with [the updated columns whose new count is below that of the walk's last
+//                candidate], by (count, unmoved before updated, order) -- all of it in LDS.  Then what mk_stage and
+//                the reduction of mk_pick would do: entries, row metadata, costs, winner, on data that is final by
+//                then (the barrier has drained the line updates).
+// At C3 the next search is done this way after 47 400 of the 49 927 kind-1 pivots (23 322 of them with updated
+// columns merged in): pivot loop 748 -> 667 ms.  The wave runs at raised priority (s_setprio): its chain of loads
+// is the longest thing in the phase and it issues few instructions.
 // Nothing here is read by the current pivot: the candidate and staging arrays were consumed by its own set-up.
 // `make ewcheck` compares every such result -- candidates, count, key and every staged entry -- with the ordinary
-// search.  Built and measured on the way, not kept: reuse of the current search's surviving candidates and their
-// staged entries instead of walking them again (never more than two of four survive and the bookkeeping costs more
-// instructions on a contended SIMD than the two round trips it saves: 715 -> 767 ms).
+// search.  Steps on the way: the whole search before the barrier; without the merge (the walk
+// is the next search's own only if no updated column has a smaller count than its last candidate: 48 % of the
+// pivots, 698 ms); reuse of the current search's surviving candidates and their staged entries instead of walking
+// them again (never more than two of four survive and the bookkeeping costs more instructions on a contended SIMD
+// than the two round trips it saves: 715 -> 767 ms, not kept).
 // ------------------------------------------------------------------------------------------------
 #ifdef BLU_SPEC_STATS
 #define SPEC_STAT(i) do { if (lane_id() == 0) atomicAdd((unsigned long long *)&D.s->prof[40 + (i)], 1ull); } while (0)
@@ -1602,10 +1603,6 @@ __device__ __forceinline__ void spec_walk(const DevGP &D, Sm *sm, Mc *mc)
     if (LC.fl(m) != m) return;
     SPEC_STAT(0);
     PROF_STAMP_L0(41);
-    // The line updates run beside this: a column that is done has its new count in tNew (set to "not yet" by the
-    // set-up).  One below the count of a candidate already decides that this search will not be the next one
-    // (spec_cond): stop at once and leave the SIMD to the updates.
-    const int nq = fa->tLnk ? sm->nzr - 1 : 0;
     int ncand = 0, total = 0, lastnz = 0;
     int nz = sm->min_colnz; // (the current search's: a lower bound of every unmoved column's count)
     bool bad = false;
@@ -1622,8 +1619,7 @@ __device__ __forceinline__ void spec_walk(const DevGP &D, Sm *sm, Mc *mc)
             while (j < m && ncand < K) {
                 const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
                 const double cmx = D.colmax[j];
-                const int kq = lane < nq ? fa->tNew[1 + lane] : 0x7fffffff;
-                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2 || __ballot(kq < znz)) {
+                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
                     bad = true;
                     break;
                 }
@@ -1664,7 +1660,7 @@ __device__ __forceinline__ bool spec_cond(const Sm *sm, const int *keys, int n)
     const Fast *fa = &sm->fa;
     if (!fa->spOk || sm->flag_small || fa->anycancel || n >= 64) return false;
     const int kq = lane < n ? keys[lane] : 0x7fffffff;
-    return __ballot(kq < fa->spLastNz) == 0ull;
+    return __ballot(kq <= 0) == 0ull; // (an empty column: the ordinary search takes it, markowitz.rs:73-78)
 }
 
 // The second half, in the finalize step (this wave has no other job there): the candidates' entries and the
@@ -1672,11 +1668,74 @@ __device__ __forceinline__ bool spec_cond(const Sm *sm, const int *keys, int n)
 // the line updates -- the cost of every eligible entry, the winner.  Publishes the result for the next search
 // (ewValid = 2).  (Staging before the barrier and only the costs here was measured too: the barrier comes later
 // by more than this step gets shorter, 699 -> 707 ms.)
-__device__ __forceinline__ void spec_finish(const DevGP &D, Sm *sm)
+__device__ __forceinline__ void spec_finish(const DevGP &D, Sm *sm, int n)
 {
     const int lane = lane_id();
     Fast *fa = &sm->fa;
-    const int ncand = fa->ncand, total = fa->cOff[ncand];
+    const int ncand = fa->ncand;
+    // ---- merge.  The next search walks, count by count, the unmoved columns of a list in their old order and then
+    // the columns this pivot appended to it, in pivot-row order.  The walk has the first K unmoved ones (counts
+    // ascending, the last one's = spLastNz); an updated column comes before the K-th candidate exactly if its new
+    // count is below spLastNz, and then every unmoved column of its count or less is among the K.  Positions:
+    //   updated column q:    #(unmoved with count <= its count) + #(entering updated columns before it by (count, q))
+    //   unmoved candidate i: i + #(entering updated columns with a count below its own)
+    // and the first K positions are the candidates of the next search.
+    {
+        const int lastnz = fa->spLastNz;
+        const int key = lane < n ? fa->tNew[1 + lane] : 0x7fffffff;
+        const unsigned long long inb = __ballot(key < lastnz);
+        if (inb) {
+            int uJ = 0, uNz = 0x7fffffff, uB = 0, uL = 0;
+            double uMx = 0.0;
+            if (lane < ncand) {
+                uJ = fa->cJ[lane];
+                uNz = fa->cNz[lane];
+                uB = fa->cB[lane];
+                uL = fa->cL[lane];
+                uMx = fa->cMx[lane];
+            }
+            int ule = 0;
+            for (int i = 0; i < ncand; i++) ule += fa->cNz[i] <= key;
+            int before = 0, below = 0;
+            unsigned long long mb = inb;
+            while (mb) {
+                const int b = __ffsll((long long)mb) - 1;
+                mb &= mb - 1;
+                const int kb = __builtin_amdgcn_readlane(key, b);
+                before += (kb < key) || (kb == key && b < lane);
+                below += kb < uNz;
+            }
+            const int posM = ule + before, posU = lane + below;
+            wave_mem_sync();
+            if (lane < ncand && posU < ncand) {
+                fa->cJ[posU] = uJ;
+                fa->cNz[posU] = uNz;
+                fa->cB[posU] = uB;
+                fa->cL[posU] = uL;
+                fa->cMx[posU] = uMx;
+            }
+            if (((inb >> lane) & 1ull) && posM < ncand) {
+                fa->cJ[posM] = fa->tJ[1 + lane];
+                fa->cNz[posM] = key;
+                fa->cB[posM] = fa->tB[1 + lane];
+                fa->cL[posM] = key;
+                fa->cMx[posM] = fa->tMx[1 + lane];
+            }
+            wave_mem_sync();
+            if (lane == 0) {
+                int off = 0;
+                for (int i = 0; i < ncand; i++) {
+                    fa->cOff[i] = off;
+                    off += fa->cL[i];
+                }
+                fa->cOff[ncand] = off;
+            }
+            wave_mem_sync();
+            SPEC_STAT(4);
+        }
+    }
+    const int total = fa->cOff[ncand];
+    if (total > STGMAX) return;
     const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
               off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
     const long long BIG = 0x7fffffffffffffffLL;
@@ -1834,7 +1893,7 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
     // wave 0 writes the U row instead and the next search waits for the barrier
     const bool spec = BLU_SPEC && early && (w == 0 || w == nw - 1) && spec_cond(sm, fa->tNew + 1, rnz1);
     if (w == 0 && early && !spec) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
-    if (w == nw - 1 && spec) spec_finish(D, sm);
+    if (w == nw - 1 && spec) spec_finish(D, sm, rnz1);
     if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
         if (lane == 0) {

@@ -7,9 +7,9 @@ from blu_amd.matrices import CONFIGS
 c = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C3"]
 cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"], c["offscale"])
 h = blu_amd.BLU(c["m"], len(ri))
-b = [h.stat(100 + i) for i in range(4)]
+b = [h.stat(100 + i) for i in range(5)]
 st = h.factorize(cp[:-1], cp[1:], ri, v)
-a = [h.stat(100 + i) for i in range(4)]
+a = [h.stat(100 + i) for i in range(5)]
 d = [int(x - y) for x, y in zip(a, b)]
 print("status", st, "kind-1 pivots", int(h.stat(54)))
-print("speculative search: started %d | walk complete (K candidates, no new count below them so far) %d | still possible after the line updates %d | became the next search %d" % tuple(d))
+print("speculative search: started %d | walk complete (K unmoved candidates) %d | still possible after the line updates %d | became the next search %d | of which with updated columns merged in %d" % (d[0], d[1], d[2], d[3], d[4]))
