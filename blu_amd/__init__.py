@@ -6,5 +6,5 @@ infrastructure.
 """
 from . import keys  # noqa: F401
 from . import blu  # noqa: F401
-from .blu import BLU, BluError, build_library, factorize_batch, gen_lp_basis, lib  # noqa: F401
+from .blu import BLU, BluError, SELFCHECK_LIB_PATH, build_library, factorize_batch, gen_lp_basis, lib  # noqa: F401
 from .maxvolume import maxvolume  # noqa: F401

@@ -46,13 +46,21 @@ class BluError(RuntimeError):
         self.status = status
 
 
-def build_library(verbose=False):
-    """Compile libblu_hip.so for gfx950 with hipcc (works without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "../libblu_hip.so"]
+SELFCHECK_LIB_PATH = os.path.join(_HERE, "libblu_hip_ewcheck.so")
+
+
+def build_library(verbose=False, selfcheck=False):
+    """Compile libblu_hip.so for gfx950 with hipcc (works without a GPU).
+
+    selfcheck=True builds libblu_hip_ewcheck.so instead: the same library with -DBLU_EWCHECK, in which the pivot loop
+    compares every early / speculative search of the next pivot with the ordinary search (candidates, count, key,
+    staged entries) and raises ST_ERROR on the first difference.  Select it with BLU_HIP_LIB=<path> (diagnostic)."""
+    target = "../libblu_hip_ewcheck.so" if selfcheck else "../libblu_hip.so"
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), target]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
-    return _LIB_PATH
+    return SELFCHECK_LIB_PATH if selfcheck else _LIB_PATH
 
 
 def lib():

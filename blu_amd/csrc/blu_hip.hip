@@ -441,7 +441,16 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
 }
 
 extern "C" const char *blu_hip_last_error(const blu_hip *h) { return h ? h->err.c_str() : "null handle"; }
-extern "C" const char *blu_hip_version(void) { return "blu_hip 0.1 (gfx950)"; }
+extern "C" const char *blu_hip_version(void)
+{
+#if defined(BLU_EWCHECK)
+    return "blu_hip 0.2 (gfx950; self-checking build: early / speculative searches verified in the kernel)";
+#elif defined(BLU_PROFILE)
+    return "blu_hip 0.2 (gfx950; phase-timing build)";
+#else
+    return "blu_hip 0.2 (gfx950)";
+#endif
+}
 extern "C" int blu_hip_device_count(void)
 {
     int n = 0;

@@ -100,3 +100,34 @@ def test_fuzz_slice_mid_size():
         pytest.fail(_stop["why"] + "\n" + text[-2000:])
     assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
     assert "all 40 cases of seed 31 from 0 identical" in text
+
+
+# ---- the self-checking library (make ewcheck, built by __graft_entry__.build()): inside the pivot loop every early and
+# every speculative search of the next pivot is compared with the ordinary search -- candidates, count, key, staged
+# entries -- and the first difference ends the factorization with ST_ERROR.  A sweep of fresh cases and a few mid-size
+# bases under it, results identical to the oracle's as everywhere else.
+@pytest.mark.parametrize("args,tag", [(["--seed", "2718", "--start", "0", "--count", "120"], "all 120 cases of seed 2718 from 0 identical"),
+                                      (["--seed", "32", "--start", "0", "--count", "12", "--mmin", "1500", "--mmax", "9000"],
+                                       "all 12 cases of seed 32 from 0 identical")], ids=["small", "mid"])
+def test_fuzz_slice_self_checking_library(args, tag):
+    if _stop["why"]:
+        pytest.skip("not started: " + _stop["why"])
+    import blu_amd
+    libpath = blu_amd.build_library(selfcheck=True)  # (a no-op when __graft_entry__.build() has run)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzz_selfcheck_s%s.log" % args[1])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")] + args + ["--log", log]
+    env = dict(os.environ, BLU_HIP_LIB=libpath)
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    except subprocess.TimeoutExpired:
+        _stop["why"] = "self-checking slice hung; last case started: %s" % _last_started(log)
+        pytest.fail(_stop["why"])
+    text = r.stdout.decode(errors="replace")
+    if r.returncode < 0 or r.returncode >= 124:
+        _stop["why"] = "self-checking slice was killed (rc %d); last case started: %s" % (r.returncode, _last_started(log))
+        pytest.fail(_stop["why"] + "\n" + text[-2000:])
+    assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
+    assert "self-checking build" in text, text[:300]  # (the child really ran on that library)
+    assert tag in text

@@ -141,6 +141,7 @@ def main():
             continue
         if blu_amd is None:
             import blu_amd  # first GPU use only when the slice begins
+            print("library:", blu_amd.lib().blu_hip_version().decode(), flush=True)
         kk, dd = run_case(blu_amd, case, c, mat, o, so, solves, log)
         kinds = [x + y for x, y in zip(kinds, kk)]
         d3 += dd
