@@ -664,11 +664,20 @@ __device__ __forceinline__ bool mk_express(const DevGP &D, Sm *sm, Mc *mc, int &
         cmx = D.colmax[j];
     }
     if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false;
-    if (idx < 0) {
-        idx = D.cidx[cb];
-        val = D.cval[cb];
+    int rb, rl, rc;
+    if (idx >= 0 && mc->e1rl[ps] >= 0) { // (left with the entry by the singleton-column pivot that made it a singleton)
+        rb = mc->e1rb[ps];
+        rl = mc->e1rl[ps];
+        rc = mc->e1rc[ps];
+    } else {
+        if (idx < 0) {
+            idx = D.cidx[cb];
+            val = D.cval[cb];
+        }
+        rb = D.rbeg[idx];
+        rl = D.rlen[idx];
+        rc = D.rcap[idx];
     }
-    const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
     const double tol = fmax(D.abstol, D.reltol * cmx);
     const double x = fabs(val);
     if (x == 0.0 || x < tol) return false;
@@ -965,7 +974,7 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
             const int sN = fa->ncand;
             const int myc = lane < sN ? fa->cJ[lane] : -1;
             // (whole search: every staged entry with its row's begin, length and capacity as well)
-            const int sT = whole ? fa->cOff[sN] : 0;
+            const int sT = whole ? fa->cOff[sN] : 1;
             int kI[2], kB[2], kL[2], kC[2];
             double kV[2];
             for (int u = 0; u < 2; u++) {
@@ -993,12 +1002,12 @@ __device__ __forceinline__ bool markowitz_fast(const DevGP &D, Sm *sm, Mc *mc, l
                 const long long BIGK = 0x7fffffffffffffffLL;
                 const long long key2 = wave_min_ll(mcb2 != BIGK ? mcb2 * 256LL + (long long)fb2 : BIGK);
                 okc = okc && key2 == key && fa->cOff[fa->ncand] == sT;
-                for (int u = 0; u < 2; u++) {
-                    const int f = lane + 64 * u;
-                    if (okc && f < sT) okc = fa->sI[f] == kI[u] && fa->sB[f] == kB[u] && fa->sL[f] == kL[u] && fa->sC[f] == kC[u] && fa->sV[f] == kV[u];
-                }
                 mcb2 = mcb;
                 fb2 = fb;
+            }
+            for (int u = 0; u < 2; u++) { // (a singleton found early: its one entry; if the ordinary search walked, that is entry 0 too)
+                const int f = lane + 64 * u;
+                if (okc && f < sT) okc = fa->sI[f] == kI[u] && fa->sB[f] == kB[u] && fa->sL[f] == kL[u] && fa->sC[f] == kC[u] && fa->sV[f] == kV[u];
             }
             okc = okc && fa->ncand == sN && nsr2 == nsr && mcb2 == mcb && fb2 == fb && (lane >= sN || fa->cJ[lane] == myc);
             if (__ballot(!okc)) {
@@ -1489,8 +1498,9 @@ __device__ __forceinline__ void fast_write_l(const DevGP &D, Sm *sm)
 // result with the ordinary search.  Not attempted: a column became empty or numerically null, a
 // cancellation fix-up is pending, row search is on, the long form of the list update was taken.
 // ------------------------------------------------------------------------------------------------
+// ebase = slot of elems[0] in the pivot row (the e1 arrays are indexed by slot)
 __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, const int *elems, const int *keys, const int *begs, const double *maxs,
-                                             int n, long long &ew_mcb, int &ew_fb)
+                                             int n, int ebase, long long &ew_mcb, int &ew_fb)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -1510,7 +1520,7 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, con
     {
         const int h1 = LinksC{D, mc}.fl(m + 1);
         const unsigned long long one = __ballot(kq == 1);
-        int j = -1, cb = 0;
+        int j = -1, cb = 0, fs = -1;
         double cmx = 0.0;
         if (h1 < m && !hcol_has(fa, h1)) {
             j = h1;
@@ -1522,12 +1532,27 @@ __device__ __forceinline__ void early_search(const DevGP &D, Sm *sm, Mc *mc, con
             j = elems[l];
             cb = begs[l];
             cmx = maxs[l];
+            // a column of two that lost its pivot-row entry: the wave that updated it left the entry that stays and
+            // the metadata of its row in LDS (fast_scol): no round trip at all
+            if (mc && ebase + l < MC_PREV && mc->e1i[ebase + l] >= 0 && mc->e1rl[ebase + l] >= 0) fs = ebase + l;
         }
         if (j >= 0) {
             if (cmx == 0.0 || !(cmx >= D.abstol)) return;
-            const int idx = D.cidx[cb];
-            const double val = D.cval[cb];
-            const int rb = D.rbeg[idx], rl = D.rlen[idx], rc = D.rcap[idx];
+            int idx, rb, rl, rc;
+            double val;
+            if (fs >= 0) {
+                idx = mc->e1i[fs];
+                val = mc->e1v[fs];
+                rb = mc->e1rb[fs];
+                rl = mc->e1rl[fs];
+                rc = mc->e1rc[fs];
+            } else {
+                idx = D.cidx[cb];
+                val = D.cval[cb];
+                rb = D.rbeg[idx];
+                rl = D.rlen[idx];
+                rc = D.rcap[idx];
+            }
             const double tol = fmax(D.abstol, D.reltol * cmx);
             const double x = fabs(val);
             if (x == 0.0 || x < tol) return;
@@ -1892,7 +1917,7 @@ __device__ __forceinline__ void fast_small(const DevGP &D, Sm *sm, Mc *mc, int p
     // [2] count lists, [3] U row and the pivot's own bookkeeping; with fewer than 4 waves (or row search)
     // wave 0 writes the U row instead and the next search waits for the barrier
     const bool spec = BLU_SPEC && early && (w == 0 || w == nw - 1) && spec_cond(sm, fa->tNew + 1, rnz1);
-    if (w == 0 && early && !spec) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, ew_mcb, ew_fb);
+    if (w == 0 && early && !spec) early_search(D, sm, mc, fa->tJ + 1, fa->tNew + 1, fa->tB + 1, fa->tMx + 1, rnz1, 1, ew_mcb, ew_fb);
     if (w == nw - 1 && spec) spec_finish(D, sm, rnz1);
     if (w == (early ? 3 : 0)) {
         fast_write_u(D, sm, 1, rnz1, -1);
@@ -1971,13 +1996,21 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
             const int src = hb ? __ffsll((long long)hb) - 1 : 0;
             const double xrj = wave_bcast_d(val, src);
             unsigned long long *wm = &sm->wmax[w];
+            // the one entry that stays in a column of two: the column is a singleton now, very likely the next pivot
+            // column.  The next search finds the entry in LDS, and the metadata of its row as well: loaded here, by
+            // the one lane that holds the entry (rows do not change in a singleton-column pivot), stored at the end.
+            const bool fw1 = mc && cl == 2 && q < MC_PREV && v && lane != src;
+            int f_rb = 0, f_rl = 0, f_rc = 0;
+            if (fw1) {
+                f_rb = D.rbeg[idx];
+                f_rl = D.rlen[idx];
+                f_rc = D.rcap[idx];
+                mc->e1i[q] = idx;
+                mc->e1v[q] = val;
+            }
             if (v && lane != src) {
                 const double x = fabs(val);
                 if (x > 0.0) atomicMax(wm, (unsigned long long)__double_as_longlong(x));
-                if (mc && cl == 2 && q < MC_PREV) { // the one entry that stays: the next search finds it in LDS
-                    mc->e1i[q] = idx;
-                    mc->e1v[q] = val;
-                }
             }
             // last entry into the hole (pivot.rs:991-993): it is in lane cl - 1
             const int last_i = wave_bcast_i(idx, cl - 1);
@@ -1995,6 +2028,11 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
                 if (mc && cl != 2 && q < MC_PREV) mc->e1i[q] = -1;
                 fa->tX[q] = xrj;
                 if (cmx == 0.0 || cmx < D.abstol) sm->flag_small = 1;
+            }
+            if (fw1) {
+                mc->e1rb[q] = f_rb;
+                mc->e1rl[q] = f_rl;
+                mc->e1rc[q] = f_rc;
             }
             continue;
         }
@@ -2014,9 +2052,10 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
             if (v && idx != pr) {
                 const double x = fabs(val);
                 if (x > cmxl) cmxl = x;
-                if (mc && cl == 2 && q < MC_PREV) { // the one entry that stays: the next search finds it in LDS
+                if (mc && cl == 2 && q < MC_PREV) { // (never here: a column of two takes the short form above)
                     mc->e1i[q] = idx;
                     mc->e1v[q] = val;
+                    mc->e1rl[q] = -1;
                 }
             }
         }
@@ -2037,7 +2076,7 @@ __device__ __forceinline__ void fast_scol(const DevGP &D, Sm *sm, Mc *mc, int pr
     __syncthreads();
     // finalize step: [0] the search of the next pivot, [1] count lists, [2] U row and bookkeeping
     const bool early = BLU_EARLY && split && !D.search_rows;
-    if (w == 0 && early) early_search(D, sm, mc, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl, ew_mcb, ew_fb);
+    if (w == 0 && early) early_search(D, sm, mc, fa->tJ, fa->tNew, fa->tB, fa->tMx, rl, 0, ew_mcb, ew_fb);
     if (w == (early ? 2 : 0)) {
         fast_write_u(D, sm, 0, rl - 1, wq);
         if (lane == 0) {

@@ -67,6 +67,7 @@ struct Mc {
     int pFl[MC_PREV];
     int e1i[MC_PREV]; // row index of the single remaining entry, -1 = not known
     double e1v[MC_PREV];
+    int e1rb[MC_PREV], e1rl[MC_PREV], e1rc[MC_PREV]; // (begin, len, cap) of that row, loaded by the wave that updated the column
 };
 
 struct Fast {
