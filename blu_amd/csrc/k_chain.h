@@ -292,6 +292,55 @@ __device__ __forceinline__ double ch_accumulate(double acc, double prod, int n)
     return acc;
 }
 
+// The same for at most 16 terms when every row of 16 lanes holds the products (lane l: term l & 15): one instruction
+// per term.  v_fmac_f64 is the one 64-bit VALU operation of gfx90a+ that takes a DPP operand, with row_newbcast:t
+// (lane t of the row to the whole row); acc = fma(term_t, +-1.0, acc) rounds once, exactly like acc +- term_t.  Three
+// instructions per term otherwise (two v_readlane and the add).  An s_nop covers the VALU-write -> DPP-read hazards (2 wait states after a write of the operand, 5 after a VALU write of EXEC)
+// of the products, which the compiler cannot see inside the asm.
+template <bool SUB>
+__device__ __forceinline__ double ch_accumulate_rows(double acc, double prod, int n)
+{
+    const double sg = SUB ? -1.0 : 1.0;
+#define CH_D(T) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(prod), "v"(sg));
+// (term 0 is the first in every path: the wait states ride in the same asm statement, where no scheduler can move them)
+#define CH_D0 asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(prod), "v"(sg));
+#define CH_TAIL(A, B, C) \
+    if (n > A) {         \
+        CH_D(A)          \
+        if (n > B) {     \
+            CH_D(B)      \
+            if (n > C) { \
+                CH_D(C)  \
+            }            \
+        }                \
+    }
+    if (n >= 4) {
+        CH_D0 CH_D(1) CH_D(2) CH_D(3)
+        if (n >= 8) {
+            CH_D(4) CH_D(5) CH_D(6) CH_D(7)
+            if (n >= 12) {
+                CH_D(8) CH_D(9) CH_D(10) CH_D(11)
+                if (n >= 16) {
+                    CH_D(12) CH_D(13) CH_D(14) CH_D(15)
+                } else {
+                    CH_TAIL(12, 13, 14)
+                }
+            } else {
+                CH_TAIL(8, 9, 10)
+            }
+        } else {
+            CH_TAIL(4, 5, 6)
+        }
+    } else if (n > 0) {
+        CH_D0
+        CH_TAIL(1, 2, 3)
+    }
+#undef CH_TAIL
+#undef CH_D0
+#undef CH_D
+    return acc;
+}
+
 // One sweep by the whole workgroup: wave 0 walks the chain, the other waves stage.  All waves must call it.
 //   INIT_OWN: the accumulator starts at the step's own value (scatter-form loops of the reference), else at 0
 //   SUB:      terms are subtracted, else added
@@ -340,8 +389,9 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
             E.xv = 0.0;
             E.sel = CH_SEL_FAR;
             const int n = nf < 0 ? 0 : (nf & (CH_HAS - 1));
-            if (lane < n) {
-                const int r = (eb + lane) & (CH_CE - 1);
+            const int li = n <= 16 ? (lane & 15) : lane; // (up to 16 entries: every row of 16 lanes holds them all, ch_accumulate_rows)
+            if (li < n) {
+                const int r = (eb + li) & (CH_CE - 1);
                 const ChOpsV v = L->ev[r];
                 E.val = v.val;
                 E.xv = v.xv;
@@ -384,7 +434,8 @@ __device__ __forceinline__ bool chain_sweep(const A &ad, ChainLds *L, int k0, in
                 double acc = rl_d(BR.init, t);
                 if (n1 > 0) {
                     const double x = E1.sel == CH_SEL_PREV ? vprev : (E1.sel >= 0 ? xw1 : E1.xv);
-                    acc = ch_accumulate<SUB>(acc, lane < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
+                    if (n1 <= 16) acc = ch_accumulate_rows<SUB>(acc, (lane & 15) < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
+                    else acc = ch_accumulate<SUB>(acc, lane < n1 ? __dmul_rn(x, E1.val) : 0.0, n1);
                 } else if (n1 < 0) { // long step: straight from global memory
                     const ChMeta M = ad.meta(k1);
                     for (int o = 0; o < M.len; o += 64) {
