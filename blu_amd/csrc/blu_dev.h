@@ -20,6 +20,17 @@
 
 #define BLU_WAVE 64
 
+// dynamic LDS of a kernel (sized at the launch); the CPU emulation build (emu/hip/hip_runtime.h) defines its own form
+#ifndef BLU_DYN_SHARED
+#define BLU_DYN_SHARED(T, name, bytes) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+// occupancy hint of a kernel (a device-only attribute)
+#ifdef BLU_EMU_BUILD
+#define BLU_WAVES_PER_EU(lo, hi)
+#else
+#define BLU_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 // Kernel exit / progress codes (Scalars::status)
 enum {
     ST_RUNNING = 0,
@@ -223,7 +234,21 @@ __device__ __forceinline__ int wave_prefix_count(unsigned long long b)
 // fence emits no instruction -- it only keeps the compiler from moving accesses across it.  (A
 // workgroup-scope fence here would drain vmcnt/lgkmcnt: one store round trip per call.)
 // Communication BETWEEN waves goes through __syncthreads().
+#ifdef BLU_EMU_BUILD // (a wave barrier that reports its caller)
+__device__ __forceinline__ void wave_mem_sync(const char *f = __builtin_FILE(), int l = __builtin_LINE()) { emu_fence("wavefront", f, l); }
+#else
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+#endif
+// The lanes of a wave execute every instruction together: "lane A loads X, then lane B stores X" needs nothing on
+// the GPU.  The CPU emulation build (emu/hip/hip_runtime.h) runs the lanes of a wave one after the other between two
+// collectives; WAVE_LOCKSTEP() marks the places that rely on lockstep and is a wave barrier there, nothing here.
+#ifdef BLU_EMU_BUILD
+#define WAVE_LOCKSTEP() emu_wave_lockstep()
+#else
+#define WAVE_LOCKSTEP() \
+    do {                \
+    } while (0)
+#endif
 
 // Broadcast of one lane's value when the source lane is the same for the whole wave (derived from a ballot):
 // v_readlane with the lane number in a scalar register -- a few cycles -- instead of __shfl, which compiles
@@ -250,6 +275,9 @@ struct OpMinLL { __device__ __forceinline__ long long operator()(long long a, lo
 struct OpSumLL { __device__ __forceinline__ long long operator()(long long a, long long b) const { return a + b; } };
 // max of non-negative doubles (|x| values): plain compare, NaN never selected (matches `if x > cmx`)
 struct OpMaxD { __device__ __forceinline__ double operator()(double a, double b) const { return b > a ? b : a; } };
+#ifdef BLU_EMU_BUILD
+template <class T, class Op> __device__ __forceinline__ T wave_allreduce(T v, Op op) { return emu_wave_allreduce(v, op); }
+#else
 template <class T, class Op> __device__ __forceinline__ T wave_allreduce(T v, Op op)
 {
     using WR = rocprim::warp_reduce<T, 64, true>;
@@ -258,6 +286,7 @@ template <class T, class Op> __device__ __forceinline__ T wave_allreduce(T v, Op
     WR().reduce(v, out, st, op);
     return out;
 }
+#endif
 __device__ __forceinline__ int wave_min_i(int v) { return wave_allreduce(v, OpMinI()); }
 __device__ __forceinline__ int wave_max_i(int v) { return wave_allreduce(v, OpMaxI()); }
 __device__ __forceinline__ int wave_sum_i(int v) { return wave_allreduce(v, OpSumI()); }

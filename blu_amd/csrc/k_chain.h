@@ -94,8 +94,13 @@ struct ChEnt {
         }                                                           \
     } while (0)
 
+#ifdef BLU_EMU_BUILD // (CPU emulation build: memory is always current; the DPP sum below through the emulator's exchange)
+__device__ __forceinline__ void ch_lds_fence() {}
+__device__ __forceinline__ void ch_vm_drain() {}
+#else
 __device__ __forceinline__ void ch_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void ch_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 __device__ __forceinline__ double ch_load_final(gdouble_p p)
 {
     // a value another wave of this workgroup stored some time ago: read past this CU's vector cache
@@ -301,9 +306,14 @@ template <bool SUB>
 __device__ __forceinline__ double ch_accumulate_rows(double acc, double prod, int n)
 {
     const double sg = SUB ? -1.0 : 1.0;
+#ifdef BLU_EMU_BUILD
+#define CH_D(T) acc = fma(__shfl(prod, (lane_id() & ~15) + T), sg, acc);
+#define CH_D0 CH_D(0)
+#else
 #define CH_D(T) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(prod), "v"(sg));
 // (term 0 is the first in every path: the wait states ride in the same asm statement, where no scheduler can move them)
 #define CH_D0 asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(prod), "v"(sg));
+#endif
 #define CH_TAIL(A, B, C) \
     if (n > A) {         \
         CH_D(A)          \

@@ -42,6 +42,7 @@ __device__ void wave_sort_segment_ik(int *key, double *val, int b, int e, int *l
 {
     const int lane = lane_id();
     const int n = e - b;
+    WAVE_LOCKSTEP(); // (the previous segment's reads of the LDS slice are done)
     for (int t = lane; t < n; t += 64) {
         lk[t] = key[b + t];
         lv[t] = val[b + t];
@@ -259,7 +260,7 @@ struct ChURows {
 // for k_stats_tail: lf = gwork[2(m+1)..], rf [3..], lb [4..], rb [5..].
 __global__ void __launch_bounds__(CHAIN_THREADS) k_stats_chains(DevLU *Ds, FinishOut *Os, RowsWs R)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
+    BLU_DYN_SHARED(unsigned char, ch_smem, sizeof(ChainLds));
     ChainLds *L = (ChainLds *)ch_smem;
     const DevG D(Ds[0]);
     const FinishOut &O = Os[0];
@@ -488,7 +489,7 @@ struct ChSolveLStage {
 __global__ void __launch_bounds__(CHAIN_THREADS) k_solve_dense_chain(DevLU *Ds, FinishOut *Os, RowsWs R, const double *rhs, double *lhs, int trans,
                                                                      int *defect)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
+    BLU_DYN_SHARED(unsigned char, ch_smem, sizeof(ChainLds));
     ChainLds *L = (ChainLds *)ch_smem;
     const DevG D(Ds[0]);
     const FinishOut &O = Os[0];

@@ -44,6 +44,7 @@ __device__ void wave_sort_segment(long long *key, double *val, int b, int e, int
 {
     const int lane = lane_id();
     const int n = e - b;
+    WAVE_LOCKSTEP(); // (the previous segment's reads of the LDS slice are done)
     for (int t = lane; t < n; t += 64) {
         lk[t] = (int)key[b + t];
         lv[t] = val[b + t];

@@ -1266,7 +1266,9 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
             wave_mem_sync();
             // something wrote list links straight to global memory since the last search (a general pivot path,
             // remove_col, the empty-column step): reload the LDS copies of the list heads
-            if (mc && mc->dirty) {
+            const bool heads_stale = mc && mc->dirty;
+            WAVE_LOCKSTEP(); // (every lane has read the flag before lane 0 clears it)
+            if (heads_stale) {
                 mc_reset(D, mc, lane, 64);
                 wave_mem_sync();
             }
@@ -1458,7 +1460,7 @@ __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 #ifndef BLU_BATCH_THREADS
 #define BLU_BATCH_THREADS 256
 #endif
-__global__ void __launch_bounds__(BLU_BATCH_THREADS) __attribute__((amdgpu_waves_per_eu(BLU_BATCH_WAVES, BLU_BATCH_WAVES)))
+__global__ void __launch_bounds__(BLU_BATCH_THREADS) BLU_WAVES_PER_EU(BLU_BATCH_WAVES, BLU_BATCH_WAVES)
 k_pivot_loop_batch(DevLU *Ds, int stop_at)
 {
     __shared__ __attribute__((aligned(16))) char raw[sizeof(Sm) - (16 - BLU_BATCH_THREADS / 64) * 64 * sizeof(double)];

@@ -33,6 +33,7 @@ __device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, 
             const int k = __shfl(key, leader);
             const unsigned long long grp = __ballot(act && key == k);
             const int tail = blink[n + k];
+            WAVE_LOCKSTEP(); // (every lane has the old tail before the group's last lane replaces it)
             if (act && key == k) {
                 const unsigned long long below = grp & lanes_below(lane);
                 const unsigned long long above = grp & ~((2ull << lane) - 1ull);

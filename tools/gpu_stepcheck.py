@@ -42,6 +42,8 @@ def make(args, cp, ri, v):
         h.set_param(K.PARAM_SEARCH_ROWS, 1 if args.search_rows else 0)
         h.set_param(K.PARAM_NZBIAS, args.nzbias)
     g.dbg_set_block(args.block)
+    if args.no_fast:
+        g.dbg_set_no_fast(True)
     return g, o
 
 
@@ -80,6 +82,7 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--search-rows", action="store_true")
     ap.add_argument("--nzbias", type=int, default=1)
+    ap.add_argument("--no-fast", action="store_true", help="general pivot paths only")
     args = ap.parse_args()
     if args.matrix == "simple":
         cp, ri, v, _, _ = simple_rs()
