@@ -19,6 +19,7 @@
 #include "k_finish.hip"
 #define BLU_NS pv_single
 #define BLU_CFG_BATCH 0
+#define BLU_CFG_WAVE 0
 #include "k_pivot.hip"
 #undef BLU_NS
 #undef BLU_CFG_BATCH
@@ -27,8 +28,17 @@
 #include "k_pivot.hip"
 #undef BLU_NS
 #undef BLU_CFG_BATCH
+#undef BLU_CFG_WAVE
+#define BLU_NS pv_wave
+#define BLU_CFG_BATCH 1
+#define BLU_CFG_WAVE 1
+#include "k_pivot.hip"
+#undef BLU_NS
+#undef BLU_CFG_BATCH
+#undef BLU_CFG_WAVE
 using pv_single::k_pivot_loop;
 using pv_batch::k_pivot_loop_batch;
+using pv_wave::k_pivot_loop_wave;
 #include "k_prep.hip"
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"
@@ -56,6 +66,7 @@ struct blu_hip {
     FinishOut *dO;
     FinishOut *oslot;
     int batch_block;   // workgroup size of the pivot kernel when this handle leads a batch
+    int pivot_kernel;  // 0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = k_pivot_loop_wave, 2 = the multi-wave kernels
     int64_t out_lcap, out_ucap;
     // owned device copies of the caller's B (blu_hip_factorize with host arrays)
     unsigned long long *ob_begin, *ob_end, *ob_i;
@@ -88,6 +99,7 @@ struct blu_hip {
     double t_phase[6]; // k_prep, k_setup, k_finish, statistics (all of it), and inside the statistics: k_rows_grid, k_stats_tail (seconds, HIP events)
     // single-matrix statistics / solve_dense on the chain pipeline (k_chain.hip)
     int chain_ok;           // 1: the device grants the LDS the chain kernels need
+    int64_t chain_defects;  // statistics chains abandoned (a bounded wait gave up) and recomputed by the one-workgroup kernel
     int *ur_len, *ur_pos;   // U rows sorted descending in pivot order (k_rows_grid)
     double *ur_val;
     int64_t ur_cap;
@@ -159,7 +171,8 @@ static void free_all(blu_hip *h)
     dfree(h->slab);
 }
 
-static bool upload_desc(blu_hip *h)
+// host copy of the descriptor brought up to date with the handle's parameters
+static void fill_desc(blu_hip *h)
 {
     DevLU &D = h->D;
     D.m = (int)h->m;
@@ -173,7 +186,11 @@ static bool upload_desc(blu_hip *h)
     D.abstol = h->abstol;
     D.reltol = h->reltol;
     D.stretch = h->stretch;
-    HIP_TRY(h, hipMemcpy(h->dslot, &D, sizeof(DevLU), hipMemcpyHostToDevice));
+}
+static bool upload_desc(blu_hip *h)
+{
+    fill_desc(h);
+    HIP_TRY(h, hipMemcpy(h->dslot, &h->D, sizeof(DevLU), hipMemcpyHostToDevice));
     return true;
 }
 static bool download_scalars(blu_hip *h)
@@ -234,6 +251,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->upd_for_nfact = -1;
     h->upd_extra = -1;
     h->chain_ok = 0;
+    h->chain_defects = 0;
     h->ur_len = h->ur_pos = nullptr;
     h->ur_val = nullptr;
     h->ur_cap = 0;
@@ -288,6 +306,11 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->dslot = h->dD;
     h->oslot = h->dO;
     h->batch_block = 256;
+    {   // diagnostic: which pivot kernel this handle launches (read once; blu_hip_dbg_set_pivot_kernel overrides)
+        const char *pk = getenv("BLU_PIVOT_KERNEL");
+        h->pivot_kernel = pk ? atoi(pk) : 0;
+        if (h->pivot_kernel < 0 || h->pivot_kernel > 2) h->pivot_kernel = 0;
+    }
     if (ok) { // chip-wide phases: as many workgroups as are certainly co-resident, at most 64 (one per CU of two XCDs' worth)
         int nb = 0, best = 1 << 30;
         const void *fns[4] = {(const void *)k_prep_grid, (const void *)k_setup_grid, (const void *)k_finish_grid, (const void *)k_rows_grid};
@@ -407,10 +430,10 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_L_FLOPS: return (double)h->sp_l_flops;
     case BLU_STAT_U_FLOPS: return (double)h->sp_u_flops;
     case BLU_STAT_NFORREST: return h->upd_for_nfact == h->nfactorize ? (double)h->ust.nforrest : 0.0;
-    case BLU_STAT_PIVOT_ERROR: return h->ust.pivot_error;
+    case BLU_STAT_PIVOT_ERROR: return h->upd_for_nfact == h->nfactorize ? h->ust.pivot_error : 0.0; // (per factorization: lu.rs:330-346)
     case BLU_STAT_R_NZ: return h->upd_for_nfact == h->nfactorize ? (double)h->ust.r_nz : 0.0;
-    case BLU_STAT_R_FLOPS: return (double)h->ust.r_flops;
-    case BLU_STAT_MAX_ETA: return h->ust.max_eta;
+    case BLU_STAT_R_FLOPS: return h->upd_for_nfact == h->nfactorize ? (double)h->ust.r_flops : 0.0;
+    case BLU_STAT_MAX_ETA: return h->upd_for_nfact == h->nfactorize ? h->ust.max_eta : 0.0;
     case BLU_STAT_NSYMPERM_TOTAL: return (double)h->ust.nsymperm_total;
     case BLU_STAT_NFORREST_TOTAL: return (double)h->ust.nforrest_total;
     case BLU_STAT_DEV_NUNSYMPERM_TOTAL: return (double)h->ust.nunsymperm_total;
@@ -429,6 +452,11 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 54: return (double)s.npivot_kind[3];
     case 55: return (double)s.npivot_kind[4];
     case 56: return (double)s.npivot_kind[5];
+    case 110: case 111: return (double)s.nfast[key - 110]; // pivots taken by the flattened paths of k_pivot_loop_wave
+    case 112: return (double)s.cused;  // entries of the column / row arena handed out (bump pointers)
+    case 113: return (double)s.rused;
+    case 114: return (double)h->D.carena_cap;
+    case 115: return (double)h->D.lcap;
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
     case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:
@@ -521,7 +549,8 @@ static bool compact_file(blu_hip *h, int which, int need)
     return upload_desc(h);
 }
 
-static bool ensure_out(blu_hip *h, int64_t ln, int64_t un)
+// upload = false: the caller copies h->O to the handle's slot itself (a batch stages all of them in one copy)
+static bool ensure_out(blu_hip *h, int64_t ln, int64_t un, bool upload = true)
 {
     if (ln > h->out_lcap) {
         dfree(h->O.l_rowidx); dfree(h->O.l_value);
@@ -533,7 +562,7 @@ static bool ensure_out(blu_hip *h, int64_t ln, int64_t un)
         if (!dalloc(h, &h->O.u_rowidx, (size_t)un) || !dalloc(h, &h->O.u_value, (size_t)un)) return false;
         h->out_ucap = un;
     }
-    HIP_TRY(h, hipMemcpy(h->oslot, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
+    if (upload) HIP_TRY(h, hipMemcpy(h->oslot, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
     return true;
 }
 
@@ -819,6 +848,13 @@ extern "C" int blu_hip_dbg_set_grid_blocks(blu_hip *h, int nblocks)
 {
     if (!h || nblocks < 1 || nblocks > SCOPE_MAX_BLOCKS) return BLU_ERROR_INVALID_ARGUMENT;
     h->grid_blocks = nblocks;
+    return BLU_OK;
+}
+// 0 = default, 1 = one wave per matrix (k_pivot_loop_wave), 2 = multi-wave workgroups (k_pivot_loop / k_pivot_loop_batch)
+extern "C" int blu_hip_dbg_set_pivot_kernel(blu_hip *h, int which)
+{
+    if (!h || which < 0 || which > 2) return BLU_ERROR_INVALID_ARGUMENT;
+    h->pivot_kernel = which;
     return BLU_OK;
 }
 extern "C" int blu_hip_dbg_set_no_fast(blu_hip *h, int on)

@@ -41,6 +41,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct int2 { int x, y; };
+inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) int4 { int x, y, z, w; };
 
 namespace emu {

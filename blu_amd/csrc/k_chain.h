@@ -80,13 +80,14 @@ struct ChEnt {
     double val;
 };
 
-// Bounded wait on LDS state written by another wave: ~2^22 polls (seconds) and the sweep is abandoned with an
-// error instead of hanging the GPU.
+// Bounded wait on LDS state written by another wave: 2^24 polls of s_sleep(1) (of the order of a second) and the
+// sweep is abandoned with an error instead of hanging the GPU; the callers report the code to the host, which
+// never uses the results of an abandoned sweep.
 #define CH_WAIT(L, cond, code)                                         \
     do {                                                            \
         int it_ = 0;                                                \
         while (!(cond)) {                                           \
-            if ((L)->abort || ++it_ > (1 << 19)) {                  \
+            if ((L)->abort || ++it_ > (1 << 24)) {                  \
                 if (!(L)->abort) (L)->abort = (code);               \
                 break;                                              \
             }                                                       \

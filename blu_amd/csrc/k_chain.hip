@@ -258,7 +258,9 @@ struct ChURows {
 // blockIdx.x = chain: 0 condest(L), 1 condest(U), 2 residual test forward, 3 residual test backward.
 // Results of chains 0 and 1 go to gwork[8(m+1)], gwork[8(m+1)+1]; the work vectors (positions) stay in gwork
 // for k_stats_tail: lf = gwork[2(m+1)..], rf [3..], lb [4..], rb [5..].
-__global__ void __launch_bounds__(CHAIN_THREADS) k_stats_chains(DevLU *Ds, FinishOut *Os, RowsWs R)
+// defect: a sweep that gave up one of its bounded waits (k_chain.h) leaves its code here (max over the four chains); the
+// host then recomputes the statistics with the one-workgroup kernel instead of trusting half-finished work vectors
+__global__ void __launch_bounds__(CHAIN_THREADS) k_stats_chains(DevLU *Ds, FinishOut *Os, RowsWs R, int *defect)
 {
     BLU_DYN_SHARED(unsigned char, ch_smem, sizeof(ChainLds));
     ChainLds *L = (ChainLds *)ch_smem;
@@ -331,6 +333,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_stats_chains(DevLU *Ds, Finis
         const ChLStage A2{D.lbeg, D.lidx, D.pinv, D.lval, lb};
         ok = ok && chain_sweep<false, false>(A2, L, m - 1, -1, m, lb, [&](int, bool has, double dot, double own, double) { return has ? own - dot : own; });
     }
+    if (!ok && threadIdx.x == 0) atomicMax(defect, L->abort ? L->abort : 99);
 }
 
 // The passes over the columns and rows of B, L, U on TAIL_BLOCKS workgroups; per-workgroup maxima to the grid scratch

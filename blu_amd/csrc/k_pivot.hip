@@ -38,7 +38,11 @@ __shared__ int g_pivot_err_line; // source line of a bounded loop that overran (
         }                                                \
     } while (0)
 
+#if BLU_CFG_WAVE
+#include "k_pivot_wave_types.h" // one wave per matrix (k_pivot_wave.hip)
+#else
 #include "k_pivot_fast_types.h" // (re-included per configuration: no include guard)
+#endif
 
 // Diagnostic build (-DBLU_PROFILE, `make prof`): thread 0 stamps the shader clock at phase boundaries
 // of the pivot loop.  The product build contains no stamps.
@@ -92,10 +96,15 @@ struct alignas(16) Sm {
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
     long long kinds[6];
+    long long nfast[2];
     int sh[40];
     long long shl[20];
     unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses
+#if BLU_CFG_WAVE
+    double swork[64]; // the dense work column of the one wave
+#else
     double swork[16 * 64]; // one dense work column per wave; LAST member: the batch kernel allocates 4 of the 16
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1173,7 +1182,9 @@ __device__ COLD bool pivot_doubleton_col(const DevGP &D, Sm *sm)
 // ------------------------------------------------------------------------------------------------
 // the persistent pivot loop: factorize_bump (factorize_bump.rs:12-49) + pivot() (pivot.rs:48-112)
 // ------------------------------------------------------------------------------------------------
+#if !BLU_CFG_WAVE
 #include "k_pivot_fast.hip"
+#endif
 
 // set-up of a pivot for the general paths (after the general searches, or for a pivot that was
 // pending when the kernel left with NEED_*): line positions and the L/U room check of pivot.rs:70-81
@@ -1200,6 +1211,9 @@ __device__ COLD void setup_pivot_general(const DevGP &D, Sm *sm)
     }
 }
 
+#if BLU_CFG_WAVE
+#include "k_pivot_wave.hip" // its own pivot loop and kernel
+#else
 // BATCH: the 4-wave workgroups of the batch kernel cannot spare a wave for the split list update and the
 // early search; leaving that code out also relieves its tighter register budget.
 // mc: the metadata cache of the single-matrix kernel (k_pivot_fast_types.h), nullptr in the batch kernel
@@ -1442,7 +1456,9 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
     }
 }
 
-#if !BLU_CFG_BATCH
+#endif // !BLU_CFG_WAVE
+#if BLU_CFG_WAVE
+#elif !BLU_CFG_BATCH
 // One matrix: all 16 waves of a CU, 128 VGPRs.
 __global__ void __launch_bounds__(1024) k_pivot_loop(DevLU *Ds, int stop_at)
 {

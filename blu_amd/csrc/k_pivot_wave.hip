@@ -1,0 +1,1039 @@
+// k_pivot_wave.hip -- the bump factorization with ONE WAVE PER MATRIX (included by k_pivot.hip, configuration
+// pv_wave): the pivot loop of a BATCH of independent bases, built for residency.
+//
+// Reference: factorize_bump (src/lu/factorize_bump.rs:12-49), markowitz (src/lu/markowitz.rs:34-123),
+// pivot_small (src/lu/pivot.rs:460-833), pivot_singleton_col (:928-1025), list_move (src/lu/list.rs:89-99).
+//
+// Why: the four-wave workgroups of k_pivot_loop_batch keep three waves waiting while one searches, and give every
+// line of a pivot a whole wave (a 20-entry column uses 20 of 64 lanes for ~270 vector instructions).  A batch is
+// bound by the instruction issue of the CUs, so this kernel (a) runs a matrix on a single wave -- no workgroup
+// barrier, every resident wave is an active instruction stream -- and (b) packs the lines of a pivot into the lanes:
+//
+//   * FLATTENED line updates.  The entries of all columns of the pivot row form one index space (column after
+//     column); a pass handles 64 of its entries, whichever columns they belong to.  Which column a lane is in comes
+//     from a 64-bit word of segment-head bits (one LDS word per pass; the columns set their bits with one LDS
+//     atomic); ranks inside a column are ballot prefixes relative to the column's first lane.  The rows of the
+//     pivot column are handled the same way.
+//   * The update proper (pivot.rs:581-690: work -= a * col, drop below droptol, append in pivot-column order) runs
+//     over (column, position) pairs, floor(64 / cnz1) columns per pass; the old values of the entries being
+//     updated cross from the first pass to the second through a small LDS matrix, group of columns by group.
+//   * The appended part of the rows (pivot.rs:752-758) runs over (row, position) pairs likewise.
+//
+// Everything result-affecting is as in the general paths of k_pivot.hip (entry order inside lines, list order,
+// arithmetic); those remain the fallback for every other shape -- they run here with a workgroup of one wave.
+//
+// Lanes of a wave run in lockstep on the GPU; the CPU emulation build (emu/hip/hip_runtime.h) needs the places that
+// rely on it marked: WAVE_LOCKSTEP().
+
+__device__ __forceinline__ unsigned wv_hslot(int k) { return ((unsigned)k * 2654435761u) >> (32 - WV_HBITS); }
+__device__ __forceinline__ void wv_probe_overrun(int line)
+{
+    g_pivot_err = 1;
+    g_pivot_err_line = line;
+}
+// every lane: empty the table (two words per lane)
+__device__ __forceinline__ void wv_hclear(Fast *fa)
+{
+    const int lane = lane_id();
+    fa->hsh[lane] = ~0ull;
+    fa->hsh[lane + 64] = ~0ull;
+}
+__device__ __forceinline__ void wv_hinsert(Fast *fa, int k, int v)
+{
+    unsigned s = wv_hslot(k);
+    const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)v;
+    for (int n = 0; n < WV_HASH; n++) {
+        const unsigned long long old = atomicCAS(&fa->hsh[s], ~0ull, want);
+        if (old == ~0ull || (int)(old >> 32) == k) return;
+        s = (s + 1) & (WV_HASH - 1);
+    }
+    wv_probe_overrun(__LINE__);
+}
+// value of key k, -1 if absent: the first two probes in straight-line code (the table is at most half full)
+__device__ __forceinline__ int wv_hfind(const Fast *fa, int k)
+{
+    const unsigned s0 = wv_hslot(k), s1 = (s0 + 1) & (WV_HASH - 1);
+    const unsigned long long x0 = fa->hsh[s0], x1 = fa->hsh[s1];
+    const bool h0 = (int)(x0 >> 32) == k, e0 = x0 == ~0ull, h1 = (int)(x1 >> 32) == k, e1 = x1 == ~0ull;
+    if (h0) return (int)(x0 & 0xffffffffull);
+    if (e0) return -1;
+    if (h1) return (int)(x1 & 0xffffffffull);
+    if (e1) return -1;
+    unsigned s = (s1 + 1) & (WV_HASH - 1);
+    for (int n = 2; n < WV_HASH; n++) {
+        const unsigned long long x = fa->hsh[s];
+        if ((int)(x >> 32) == k) return (int)(x & 0xffffffffull);
+        if (x == ~0ull) return -1;
+        s = (s + 1) & (WV_HASH - 1);
+    }
+    wv_probe_overrun(__LINE__);
+    return -1;
+}
+
+// exclusive prefix sum over the wave; *total = sum
+__device__ __forceinline__ int wv_excl_scan(int v, int *total)
+{
+    const int inc = wave_incl_scan_i(v);
+    *total = __builtin_amdgcn_readlane(inc, 63);
+    return inc - v;
+}
+// 64-bit mask helpers (per-lane constants of the paired passes)
+__device__ __forceinline__ unsigned long long wv_bits_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// What the search lays out for the pivot functions, one value per lane:
+//   lanes c < rnz1: column slot c+1 of the pivot row;  lane rnz1: the pivot column (its list links only)
+//   lanes p < cnz1: row slot p+1 of the pivot column (kind 1)
+struct WvLines {
+    int j, cb, cl, cap, fl, bl; // column: index, begin, length, capacity, count-list links
+    int i, rb, rl, rc;          // row: index, begin, length, capacity
+    double pv;                  // pivot-column value of that row
+};
+
+// ------------------------------------------------------------------------------------------------
+// Batched list_move of the pivot row's columns + removal of the pivot column (list.rs:81-99), ONE pass.
+// Lane c < n moves element e to the list of `key` (key < 0: not moved); lane n (isgone) only unlinks its
+// element.  fl/bl = the element's links as loaded by the search.  The membership test "is this neighbour moved
+// too" is the column hash (value = slot; slot s lives in lane s-1, slot 0 = the pivot column in lane n).
+// Sequential list_moves leave every list as [untouched elements in old order][moved ones in move order], so
+// "unlink all, append all in lane order" is the same thing (see wave_list_move_batch, k_pivot.hip).
+// Returns the smallest key > 0 (or big).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wv_lane_of(const Fast *fa, int e, bool want, int n)
+{
+    if (!want) return -1;
+    const int s = wv_hfind(fa, e);
+    return s < 0 ? -1 : (s == 0 ? n : s - 1);
+}
+__device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int key, bool act, bool isgone, int fl, int bl, int n, int big)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    const bool unl = act || isgone;
+    int t = 0;
+    if (act) t = D.cblink[m + key]; // tail of the new list as it is BEFORE the unlinks
+    // lanes of equal key meet in an LDS word indexed by the key (all-zero between calls); large keys by ballots
+    unsigned long long mygrp = 0ull;
+    if (!__ballot(act && key >= WV_ZW)) {
+        if (act) atomicOr(&fa->zw[key], 1ull << lane);
+        wave_mem_sync();
+        if (act) mygrp = fa->zw[key];
+        WAVE_LOCKSTEP();
+        if (act) fa->zw[key] = 0ull;
+    } else {
+        unsigned long long active = __ballot(act);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int k = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long grp = __ballot(act && key == k);
+            if (key == k) mygrp = grp;
+            active &= ~grp;
+        }
+    }
+    const unsigned long long below = mygrp & lanes_below(lane);
+    const unsigned long long above = lane < 63 ? mygrp & ~((2ull << lane) - 1ull) : 0ull;
+    const int prevl = below ? 63 - __clzll((long long)below) : -1;
+    const int nextl = above ? __ffsll((long long)above) - 1 : -1;
+    const int eprev = __shfl(e, prevl >= 0 ? prevl : lane), enext = __shfl(e, nextl >= 0 ? nextl : lane);
+    const int minall = wave_min_i(act && key > 0 ? key : big);
+    // lanes holding my successor / my predecessor / the old tail of my new list
+    int sl = wv_lane_of(fa, fl, unl && fl < m, n), pl = wv_lane_of(fa, bl, unl && bl < m, n), tl = wv_lane_of(fa, t, act && t < m, n);
+    const bool first = unl && pl < 0; // first of a run of moved neighbours
+    // first unmoved element after / before every moved one: pointer doubling over the lanes
+    int fs = fl, fp = bl;
+    for (int round = 0; round < 7; round++) {
+        if (!__ballot((unl && sl >= 0) || (unl && pl >= 0))) break;
+        const int srcs = sl >= 0 ? sl : lane, srcp = pl >= 0 ? pl : lane;
+        const int fs2 = __shfl(fs, srcs), sl2 = __shfl(sl, srcs);
+        const int fp2 = __shfl(fp, srcp), pl2 = __shfl(pl, srcp);
+        if (sl >= 0) {
+            fs = fs2;
+            sl = sl2;
+        }
+        if (pl >= 0) {
+            fp = fp2;
+            pl = pl2;
+        }
+    }
+    if (first) { // link the run's unmoved predecessor to its unmoved successor
+        D.cflink[bl] = fs;
+        D.cblink[fs] = bl;
+    }
+    // the old tail is being moved itself: the real tail is its nearest unmoved predecessor
+    const int tfix = __shfl(fp, tl >= 0 ? tl : lane);
+    if (act && tl >= 0) t = tfix;
+    if (isgone) { // list.rs:84-85: a removed element links to itself
+        D.cflink[e] = e;
+        D.cblink[e] = e;
+    }
+    WAVE_LOCKSTEP(); // unlink stores before append stores (one address may get both; a wave's stores keep their order)
+    if (act) {
+        D.cblink[e] = prevl >= 0 ? eprev : t;
+        D.cflink[e] = nextl >= 0 ? enext : m + key;
+        if (prevl < 0) D.cflink[t] = e;
+        if (nextl < 0) D.cblink[m + key] = e;
+    }
+    wave_mem_sync();
+    return minall;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Search (markowitz.rs:34-123, search_rows == 0) + pivot set-up.  Returns false if the shape is outside what this
+// path handles (nothing modified: the caller runs markowitz_wave).  On true: sm->pr / sm->pc are set (pr < 0: an
+// empty column was chosen; both < 0: error raised), fa->kind says which pivot function runs, L holds the lines.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost * 256 + position must fit 64 bits)
+    const int nz0 = sm->min_colnz;
+    if (nz0 < 1) return false;
+    // heads of list 0 (lane 0) and of lists nz0 .. nz0+62 (lanes 1..63), one gather
+    const int kk = lane == 0 ? 0 : nz0 + lane - 1;
+    const int h = kk <= m ? D.cflink[m + kk] : m + kk;
+    const int h0 = __builtin_amdgcn_readlane(h, 0);
+    if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
+        if (lane == 0) {
+            sm->pc = h0;
+            sm->pr = -1;
+            fa->kind = 0;
+        }
+        wave_mem_sync();
+        return true;
+    }
+    unsigned long long ne = __ballot(lane >= 1 && kk <= m && h != m + kk);
+    if (!ne) return false; // (a long stretch of empty lists: the general search skips them 64 at a time)
+    const int left = m - sm->rank - sm->rankdef; // every active column is in a count list; list 0 is empty
+    const int nsearched = left < K ? left : K;
+
+    int pc, pr, nzc, pcb, nzr, where, found_nz;
+    if (nz0 == 1 && (ne & 2ull)) {
+        // ---- column singleton: its one entry costs 0 and no later candidate can be strictly cheaper
+        // (markowitz.rs:105); the reference still looks at maxsearch columns, which only shows in nsearch_pivot
+        pc = __builtin_amdgcn_readlane(h, 1);
+        pcb = D.cbeg[pc];
+        const int cl = D.clen[pc];
+        const double cmx = D.colmax[pc];
+        if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false; // (the general search raises the error)
+        pr = D.cidx[pcb];
+        const double x = fabs(D.cval[pcb]);
+        const double tol = fmax(D.abstol, D.reltol * cmx);
+        if (x == 0.0 || x < tol) return false;
+        nzc = 1;
+        nzr = D.rlen[pr];
+        where = 0;
+        found_nz = 1;
+    } else {
+        // ---- walk the lists to the first K columns (dependent loads: link + metadata of one column at a time)
+        int ncand = 0, total = 0;
+        bool bad = false;
+        found_nz = -1;
+        while (ne && ncand < K && !bad) {
+            const int b = __ffsll((long long)ne) - 1;
+            ne &= ne - 1;
+            int j = __builtin_amdgcn_readlane(h, b);
+            const int znz = nz0 + b - 1;
+            int guard = 0;
+            while (j < m && ncand < K) {
+                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
+                const double cmx = D.colmax[j];
+                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = znz;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = cl;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                if (found_nz < 0) found_nz = znz;
+                total += cl;
+                ncand++;
+                j = fl;
+            }
+        }
+        if (bad) return false; // reference: assert / D2; the general search raises it
+        if (ncand < nsearched) return false; // more columns exist in lists beyond nz0+62
+        if (total > WV_STG) return false;
+        if (lane == 0) fa->cOff[ncand] = total;
+        wave_mem_sync();
+        const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
+                  off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
+        // ---- all candidate entries in one flattened pass (two for > 64): cost of every eligible entry; the
+        // reference's sequential strict-< scan is the lexicographic minimum over (cost, flat position)
+        const long long BIG = 0x7fffffffffffffffLL;
+        long long mcb = BIG;
+        int idx0 = 0, idx1 = 0, rl0 = 0, rl1 = 0;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int f = u * 64 + lane;
+            if (f < total) {
+                const int c = (f >= off1) + (f >= off2) + (f >= off3);
+                const int pos = fa->cB[c] + f - fa->cOff[c];
+                const int idx = D.cidx[pos];
+                const double val = D.cval[pos];
+                const int rl = D.rlen[idx];
+                const double tol = fmax(D.abstol, D.reltol * fa->cMx[c]);
+                const double x = fabs(val);
+                if (!(x == 0.0 || x < tol)) {
+                    const long long key = (long long)(fa->cNz[c] - 1) * (long long)(rl - 1) * 256LL + (long long)f;
+                    if (key < mcb) mcb = key;
+                }
+                if (u == 0) {
+                    idx0 = idx;
+                    rl0 = rl;
+                } else {
+                    idx1 = idx;
+                    rl1 = rl;
+                }
+            }
+        }
+        const long long best = wave_min_ll(mcb);
+        if (best == BIG) return false; // no eligible entry: cannot happen; the general search raises it
+        const int fsel = (int)(best & 255LL);
+        const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
+        pc = fa->cJ[csel];
+        nzc = fa->cL[csel];
+        pcb = fa->cB[csel];
+        where = fsel - fa->cOff[csel];
+        pr = __builtin_amdgcn_readlane(fsel < 64 ? idx0 : idx1, fsel & 63);
+        nzr = __builtin_amdgcn_readlane(fsel < 64 ? rl0 : rl1, fsel & 63);
+    }
+    const int prb = D.rbeg[pr];
+    int exit_code = 0, need = 0;
+    // room in L and U (pivot.rs:70-81)
+    if (sm->lused + (nzc - 1) > D.lcap) {
+        exit_code = ST_NEED_L;
+        need = nzc - 1;
+    } else if (sm->uused + (nzr - 1) > D.ucap) {
+        exit_code = ST_NEED_U;
+        need = nzr - 1;
+    }
+    if (lane == 0) {
+        sm->pr = pr;
+        sm->pc = pc;
+        sm->pcb = pcb;
+        sm->prb = prb;
+        sm->nzc = nzc;
+        sm->nzr = nzr;
+        sm->nsearch += nsearched;
+        sm->min_colnz = found_nz;
+        sm->flag_small = 0;
+        sm->ncancel = 0;
+        fa->anycancel = 0;
+        if (exit_code) {
+            sm->exit_code = exit_code;
+            sm->need = need;
+        }
+    }
+    DEV_CHECK(S, nzr >= 1 && nzc >= 1);
+    int kind = 0;
+    if (nzr >= 2 && nzr <= WV_SLOTS && !exit_code) {
+        if (nzc == 1) kind = 2;
+        else if (nzc >= 3 && nzc <= WV_SLOTS) kind = 1; // (64 lanes hold the pivot column: cnz1 <= 63)
+    }
+    if (kind == 0) {
+        if (lane == 0) fa->kind = 0;
+        wave_mem_sync();
+        return true;
+    }
+    // ---- lay out the pivot: pivot row (and column) into slot order, metadata of every line they touch
+    const int rnz1 = nzr - 1, cnz1 = nzc - 1;
+    const int jq = lane < nzr ? D.ridx[prb + lane] : -1;
+    int ci = -1;
+    double cv = 0.0;
+    if (kind == 1 && lane < nzc) {
+        ci = D.cidx[pcb + lane];
+        cv = D.cval[pcb + lane];
+    }
+    const unsigned long long hb = __ballot(jq == pc);
+    if (!hb) {
+        DEV_CHECK(S, false);
+        if (lane == 0) {
+            sm->pc = -1;
+            sm->pr = -1;
+            fa->kind = 0;
+        }
+        wave_mem_sync();
+        return true;
+    }
+    const int wpos = __ffsll((long long)hb) - 1;
+    if (lane < nzr) {
+        // kind 1: pivot column swapped with the first entry (pivot.rs:185); kind 2: taken out, order kept (:959-965)
+        const int slot = kind == 1 ? (lane == wpos ? 0 : (lane == 0 ? wpos : lane)) : (lane == wpos ? 0 : (lane < wpos ? lane + 1 : lane));
+        fa->tJ[slot] = jq;
+    }
+    if (kind == 1 && lane < nzc) {
+        const int slot = lane == where ? 0 : (lane == 0 ? where : lane); // pivot.rs:169-170
+        fa->pI[slot] = ci;
+        fa->pV[slot] = cv;
+    }
+    wave_mem_sync();
+    L.j = lane <= rnz1 ? fa->tJ[lane < rnz1 ? lane + 1 : 0] : -1; // lane rnz1: the pivot column
+    L.cb = L.cl = L.cap = L.fl = L.bl = 0;
+    if (lane <= rnz1) {
+        L.fl = D.cflink[L.j];
+        L.bl = D.cblink[L.j];
+    }
+    if (lane < rnz1) {
+        L.cb = D.cbeg[L.j];
+        L.cl = D.clen[L.j];
+        L.cap = D.ccap[L.j];
+    }
+    L.i = -1;
+    L.rb = L.rl = L.rc = 0;
+    L.pv = 0.0;
+    if (kind == 1) {
+        if (lane < cnz1) {
+            L.i = fa->pI[lane + 1];
+            L.pv = fa->pV[lane + 1];
+            L.rb = D.rbeg[L.i];
+            L.rl = D.rlen[L.i];
+            L.rc = D.rcap[L.i];
+        }
+        if (fa->pI[0] != pr) DEV_CHECK(S, false);
+    }
+    // sizes of the flattened phases; room in the arenas if every line had to be re-appended (pivot.rs:156-208)
+    long long gc = 0, gr = 0;
+    if (kind == 1 && lane < rnz1) {
+        const int n = L.cl + cnz1;
+        gc = n + stretch_of(D.stretch, n) + D.pad;
+    }
+    if (kind == 1 && lane < cnz1) {
+        const int n = L.rl + rnz1;
+        gr = n + stretch_of(D.stretch, n) + D.pad;
+    }
+    const long long tboth = wave_sum_ll(((long long)L.cl << 32) | (long long)(unsigned)L.rl);
+    if ((tboth >> 32) > WV_TMAX || (tboth & 0xffffffffLL) > WV_TMAX) kind = 0;
+    if (kind == 1) {
+        const long long both = wave_sum_ll((gc << 32) | (gr & 0xffffffffLL));
+        if ((long long)sm->cused + (both >> 32) > (long long)D.carena_cap || (long long)sm->rused + (both & 0xffffffffLL) > (long long)D.rarena_cap)
+            kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
+    }
+    if (lane == 0) {
+        fa->kind = kind;
+        fa->where = wpos;
+    }
+    wave_mem_sync();
+    return true;
+}
+
+// Segment bookkeeping of a flattened pass.  `hw` = head bits of this pass, `cbv` = (slot of the last line begun
+// before this pass); returns this lane's slot and tells whether it is the first / last lane of its line IN THIS PASS.
+struct WvSeg {
+    int c;
+    bool head, tail;
+};
+__device__ __forceinline__ WvSeg wv_segment(unsigned long long hw, int cbv, bool valid, bool lastflat)
+{
+    const int lane = lane_id();
+    const int own = (int)((hw >> lane) & 1ull);
+    WvSeg s;
+    s.c = cbv + wave_prefix_count(hw) + own;
+    s.head = valid && (own || lane == 0);
+    s.tail = valid && (lane == 63 || lastflat || (((hw >> 1) >> lane) & 1ull));
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pivot_small (pivot.rs:460-833), pivot row of <= 64 entries
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &L, int pr, int pc, int nz_col, int nz_row)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int cnz1 = nz_col - 1, rnz1 = nz_row - 1;
+    const double pivot = fa->pV[0];
+    DEV_CHECK(S, pivot != 0.0);
+    const double droptol = D.droptol;
+
+    // ---- rows of the pivot column -> position (the reference's `marked`, pivot.rs:219-224)
+    wv_hclear(fa);
+    wave_mem_sync();
+    if (lane < cnz1) wv_hinsert(fa, L.i, lane);
+    int Tc;
+    const int coff = wv_excl_scan(lane < rnz1 ? L.cl : 0, &Tc);
+    if (lane < rnz1) {
+        fa->sBO[lane] = make_int2(L.cb, coff);
+        fa->sCnt[lane] = 0;
+    }
+    wave_mem_sync();
+
+    // ================= column file update (pivot.rs:566-691) =================
+    // per-lane constants of the paired pass: lane = (column cl_l of the pass, position p_l)
+    const int Cper = 64 / cnz1;
+    const int cl_l = lane / cnz1, p_l = lane - cl_l * cnz1;
+    const bool pairlane = cl_l < Cper;
+    const int segs = cl_l * cnz1;
+    const unsigned long long segbelow = wv_bits_below(segs);
+    const unsigned long long segmask = pairlane ? (wv_bits_below(cnz1) << segs) : 0ull;
+    const double pv_l = fa->pV[1 + p_l];
+    const int pi_l = fa->pI[1 + p_l];
+    int Gc = WV_WCAP / cnz1; // columns per group (their old values fit the LDS matrix)
+    if (Gc < 1) Gc = 1;
+    int nk1 = 0, dst = L.cb, newcap = L.cap; // lane = column: kept entries, new begin, new capacity
+    double xrj = 0.0;
+    int cused = sm->cused, nexp = 0, nd3 = 0;
+    bool anyc = false;
+
+    for (int c0 = 0; c0 < rnz1; c0 += Gc) {
+        const int c1 = min(c0 + Gc, rnz1);
+        const int f0 = __builtin_amdgcn_readlane(coff, c0);
+        const int f1 = c1 < rnz1 ? __builtin_amdgcn_readlane(coff, c1) : Tc;
+        const int Tg = f1 - f0;
+        const bool ing = lane >= c0 && lane < c1;
+        if (ing) {
+            const int o = coff - f0;
+            atomicOr(&fa->zw[o >> 6], 1ull << (o & 63));
+        }
+        wave_mem_sync();
+        // ---- pass A: every entry of the group's columns.  Entries whose row is in the pivot column leave the
+        // column (their value goes to W); the others are compressed in place, keeping their order
+        int cbv = c0 - 1;
+        for (int k = 0; k * 64 < Tg; k++) {
+            const unsigned long long hw = fa->zw[k];
+            WAVE_LOCKSTEP();
+            if (lane == 0) fa->zw[k] = 0ull;
+            const int f = k * 64 + lane;
+            const bool valid = f < Tg;
+            const WvSeg sg = wv_segment(hw, cbv, valid, f == Tg - 1);
+            cbv += __popcll(hw);
+            int2 bo = make_int2(0, 0);
+            int e = 0, idx = -1;
+            double val = 0.0;
+            if (valid) {
+                bo = fa->sBO[sg.c];
+                e = f + f0 - bo.y;
+                idx = D.cidx[bo.x + e];
+                val = D.cval[bo.x + e];
+            }
+            const int p = valid ? wv_hfind(fa, idx) : -1;
+            const bool hit = valid && p >= 0;
+            const bool keep = valid && !hit;
+            const bool ispr = keep && idx == pr;
+            if (hit) fa->W[(sg.c - c0) * cnz1 + p] = val;
+            const unsigned long long kb = __ballot(keep);
+            const int pre = wave_prefix_count(kb);
+            if (sg.head) fa->sSeg[sg.c] = pre - fa->sCnt[sg.c];
+            wave_mem_sync();
+            const int t = valid ? pre - fa->sSeg[sg.c] : 0;
+            if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
+            if (ispr) {
+                fa->sX[sg.c] = val;
+                fa->sW[sg.c] = t;
+            } else if (keep) {
+                if (t == 0) { // it goes where the pivot-row entry was (the swap of pivot.rs:261-262): at the line's end
+                    fa->sK0i[sg.c] = idx;
+                    fa->sK0v[sg.c] = val;
+                } else {
+                    D.cidx[bo.x + t - 1] = idx;
+                    D.cval[bo.x + t - 1] = val;
+                }
+                atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
+            }
+        }
+        wave_mem_sync();
+        // ---- per column: kept count, room (file_reappend, file.rs:56-85), the deferred first entry, multiplier
+        bool reloc = false;
+        if (ing) {
+            const int cnt = fa->sCnt[lane], w = fa->sW[lane];
+            DEV_CHECK(S, cnt >= 1);
+            nk1 = cnt - 1;
+            const int need = nk1 + cnz1;
+            reloc = need > L.cap;
+            if (reloc) newcap = need + stretch_of(D.stretch, need) + D.pad;
+            if (w > 0) {
+                D.cidx[L.cb + w - 1] = fa->sK0i[lane];
+                D.cval[L.cb + w - 1] = fa->sK0v[lane];
+            }
+            xrj = fa->sX[lane];
+        }
+        const unsigned long long rlb = __ballot(reloc);
+        if (rlb) { // (uniform)
+            int tot;
+            const int ex = wv_excl_scan(reloc ? newcap : 0, &tot);
+            if (reloc) dst = cused + ex;
+            cused += tot;
+            nexp += __popcll(rlb);
+            wave_mem_sync();
+            unsigned long long rest = rlb;
+            while (rest) { // copy the kept part of a re-appended column (one column at a time: not the common case)
+                const int b = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int src = __builtin_amdgcn_readlane(L.cb, b), nn = __builtin_amdgcn_readlane(nk1, b), dd = __builtin_amdgcn_readlane(dst, b);
+                for (int t = lane; t < nn; t += 64) {
+                    D.cidx[dd + t] = D.cidx[src + t];
+                    D.cval[dd + t] = D.cval[src + t];
+                }
+            }
+        }
+        if (ing) {
+            fa->sX[lane] = xrj / pivot;
+            fa->sDst[lane] = dst + nk1;
+        }
+        wave_mem_sync();
+        // ---- pass B: (column, position) pairs: work -= a * col (pivot.rs:623-625), append what stays above
+        // droptol in pivot-column order (:630-664)
+        int wbase = 0;
+        for (int cb0 = c0; cb0 < c1; cb0 += Cper, wbase += Cper * cnz1) {
+            const int c = cb0 + cl_l;
+            const bool act = pairlane && c < c1;
+            double old = 0.0, a = 0.0;
+            int dd = 0;
+            if (act) {
+                old = fa->W[wbase + lane];
+                fa->W[wbase + lane] = 0.0;
+                a = fa->sX[c];
+                dd = fa->sDst[c];
+            }
+            const double x = mulsub(old, a, pv_l);
+            const double ax = fabs(x);
+            const bool kx = act && ax > droptol;
+            const unsigned long long kxb = __ballot(kx);
+            if (kx) {
+                const int rank = wave_prefix_count(kxb) - __popcll(kxb & segbelow);
+                D.cidx[dd + rank] = pi_l;
+                D.cval[dd + rank] = x;
+                atomicMax(&fa->sMax[c], (unsigned long long)__double_as_longlong(ax));
+            }
+            if (act && p_l == 0) {
+                const unsigned long long cm = (~kxb & segmask) >> segs; // cancelled positions (pivot.rs:656-660)
+                fa->sNew[c] = __popcll(kxb & segmask);
+                fa->sM[c] = cm;
+                if (cm) {
+                    anyc = true;
+                    nd3 += __popcll(cm >> 31);
+                }
+            }
+        }
+        wave_mem_sync();
+    }
+
+    // ---- per column: new metadata, U row (pivot.rs:666-672), new list key
+    int newlen = -1;
+    bool tiny = false;
+    if (lane < rnz1) {
+        newlen = nk1 + fa->sNew[lane];
+        const double cmx = __longlong_as_double((long long)fa->sMax[lane]);
+        fa->sMax[lane] = 0ull;
+        D.cbeg[L.j] = dst;
+        D.clen[L.j] = newlen;
+        D.ccap[L.j] = newcap;
+        D.colmax[L.j] = cmx;
+        tiny = cmx == 0.0 || cmx < D.abstol;
+    }
+    const bool ku = lane < rnz1 && fabs(xrj) > droptol;
+    const unsigned long long kub = __ballot(ku);
+    int uused = sm->uused;
+    if (ku) {
+        const int d = uused + wave_prefix_count(kub);
+        D.uidx[d] = L.j;
+        D.uval[d] = xrj;
+    }
+    uused += __popcll(kub);
+    const unsigned long long tinyb = __ballot(tiny);
+    const unsigned long long anycb = __ballot(anyc);
+
+    // ================= row file update (pivot.rs:695-775) =================
+    // columns of the pivot row -> slot (slot 0 = the pivot column): membership for the rows and for the list move
+    wv_hclear(fa);
+    wave_mem_sync();
+    if (lane <= rnz1) wv_hinsert(fa, L.j, lane < rnz1 ? lane + 1 : 0);
+    int Tr;
+    const int roff = wv_excl_scan(lane < cnz1 ? L.rl : 0, &Tr);
+    if (lane < cnz1) {
+        fa->sBO[lane] = make_int2(L.rb, roff);
+        fa->sCnt[lane] = 0;
+        atomicOr(&fa->zw[roff >> 6], 1ull << (roff & 63));
+    }
+    wave_mem_sync();
+    {
+        int cbv = -1;
+        for (int k = 0; k * 64 < Tr; k++) {
+            const unsigned long long hw = fa->zw[k];
+            WAVE_LOCKSTEP();
+            if (lane == 0) fa->zw[k] = 0ull;
+            const int f = k * 64 + lane;
+            const bool valid = f < Tr;
+            const WvSeg sg = wv_segment(hw, cbv, valid, f == Tr - 1);
+            cbv += __popcll(hw);
+            int2 bo = make_int2(0, 0);
+            int e = 0, j = -1;
+            if (valid) {
+                bo = fa->sBO[sg.c];
+                e = f - bo.y;
+                j = D.ridx[bo.x + e];
+            }
+            const bool keep = valid && wv_hfind(fa, j) < 0; // overlap with the pivot row leaves, pivot column included
+            const unsigned long long kb = __ballot(keep);
+            const int pre = wave_prefix_count(kb);
+            if (sg.head) fa->sSeg[sg.c] = pre - fa->sCnt[sg.c];
+            wave_mem_sync();
+            const int t = valid ? pre - fa->sSeg[sg.c] : 0;
+            if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
+            if (keep && t != e) D.ridx[bo.x + t] = j;
+        }
+    }
+    wave_mem_sync();
+    int rnk = 0, rdst = L.rb, rnewcap = L.rc;
+    int rused = sm->rused;
+    {
+        bool reloc = false;
+        if (lane < cnz1) {
+            rnk = fa->sCnt[lane];
+            DEV_CHECK(S, rnk < L.rl); // the pivot-column entry at least has left
+            const int need = rnk + rnz1;
+            reloc = need > L.rc;
+            if (reloc) rnewcap = need + stretch_of(D.stretch, need) + D.pad;
+        }
+        const unsigned long long rlb = __ballot(reloc);
+        if (rlb) {
+            int tot;
+            const int ex = wv_excl_scan(reloc ? rnewcap : 0, &tot);
+            if (reloc) rdst = rused + ex;
+            rused += tot;
+            nexp += __popcll(rlb);
+            unsigned long long rest = rlb;
+            while (rest) {
+                const int b = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int src = __builtin_amdgcn_readlane(L.rb, b), nn = __builtin_amdgcn_readlane(rnk, b), dd = __builtin_amdgcn_readlane(rdst, b);
+                for (int t = lane; t < nn; t += 64) D.ridx[dd + t] = D.ridx[src + t];
+            }
+        }
+        if (lane < cnz1) fa->sDst[lane] = rdst + rnk;
+    }
+    wave_mem_sync();
+    // ---- append the pattern of the pivot row, minus the cancelled positions (pivot.rs:752-758): (row, position) pairs
+    int rnew = rnk + rnz1;
+    {
+        const int Rper = 64 / rnz1;
+        const int pl_l = lane / rnz1, q_l = lane - pl_l * rnz1;
+        const bool rpair = pl_l < Rper;
+        const int rsegs = pl_l * rnz1;
+        const unsigned long long rsegbelow = wv_bits_below(rsegs);
+        const unsigned long long rsegmask = rpair ? (wv_bits_below(rnz1) << rsegs) : 0ull;
+        const int tj_l = fa->tJ[1 + q_l];
+        const unsigned long long cm_l = anycb ? fa->sM[q_l] : 0ull;
+        for (int p0 = 0; p0 < cnz1; p0 += Rper) {
+            const int p = p0 + pl_l;
+            const bool act = rpair && p < cnz1;
+            const bool ok = act && ((cm_l >> p) & 1ull) == 0ull;
+            const unsigned long long okb = __ballot(ok);
+            if (ok) {
+                const int rank = wave_prefix_count(okb) - __popcll(okb & rsegbelow);
+                D.ridx[fa->sDst[p] + rank] = tj_l;
+            }
+            if (anycb && act && q_l == 0) fa->sNew[p] = __popcll(okb & rsegmask);
+        }
+        if (anycb) {
+            wave_mem_sync();
+            if (lane < cnz1) rnew = rnk + fa->sNew[lane];
+        }
+    }
+    if (lane < cnz1) {
+        D.rbeg[L.i] = rdst;
+        D.rlen[L.i] = rnew;
+        D.rcap[L.i] = rnewcap;
+    }
+
+    // ---- L column (pivot.rs:778-790)
+    double lx = 0.0;
+    if (lane < cnz1) lx = L.pv / pivot;
+    const bool kl = lane < cnz1 && fabs(lx) > droptol;
+    const unsigned long long klb = __ballot(kl);
+    int lused = sm->lused;
+    if (kl) {
+        const int d = lused + wave_prefix_count(klb);
+        D.lidx[d] = L.i;
+        D.lval[d] = lx;
+    }
+    lused += __popcll(klb);
+
+    // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
+    // pivot-row order; the pivot column leaves
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2);
+
+    // ---- cleanup (pivot.rs:792-800)
+    if (lane == 0) {
+        const int rank = sm->rank;
+        D.ubeg[rank + 1] = uused;
+        D.lbeg[rank + 1] = lused;
+        sm->uused = uused;
+        sm->lused = lused;
+        sm->cused = cused;
+        sm->rused = rused;
+        sm->nexpand += nexp;
+        if (mn < sm->min_colnz) sm->min_colnz = mn;
+        if (tinyb) sm->flag_small = 1;
+        D.colmax[pc] = pivot;
+        D.clen[pc] = 0;
+        D.rlen[pr] = 0;
+        sm->kinds[3]++;
+        sm->nfast[0]++;
+    }
+    const int d3all = wave_sum_i(nd3);
+    if (lane == 0 && d3all) sm->d3 += d3all;
+    wave_mem_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pivot_singleton_col (pivot.rs:928-1025), pivot row of <= 64 entries: every column of the pivot row loses its
+// pivot-row entry (the column's last entry moves into the hole, :991-993); no values change.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L, int pr, int pc, int nz_row)
+{
+    const int lane = lane_id();
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int rnz1 = nz_row - 1;
+    const double pivot = D.cval[sm->pcb];
+    DEV_CHECK(S, pivot != 0.0);
+
+    wv_hclear(fa);
+    wave_mem_sync();
+    if (lane <= rnz1) wv_hinsert(fa, L.j, lane < rnz1 ? lane + 1 : 0);
+    int Tc;
+    const int coff = wv_excl_scan(lane < rnz1 ? L.cl : 0, &Tc);
+    if (lane < rnz1) {
+        fa->sBO[lane] = make_int2(L.cb, coff);
+        fa->sCnt[lane] = L.cl;
+        fa->sW[lane] = -1;
+        atomicOr(&fa->zw[coff >> 6], 1ull << (coff & 63));
+    }
+    wave_mem_sync();
+    int cbv = -1;
+    for (int k = 0; k * 64 < Tc; k++) {
+        const unsigned long long hw = fa->zw[k];
+        WAVE_LOCKSTEP();
+        if (lane == 0) fa->zw[k] = 0ull;
+        const int f = k * 64 + lane;
+        const bool valid = f < Tc;
+        const WvSeg sg = wv_segment(hw, cbv, valid, f == Tc - 1);
+        cbv += __popcll(hw);
+        if (valid) {
+            const int2 bo = fa->sBO[sg.c];
+            const int e = f - bo.y;
+            const int idx = D.cidx[bo.x + e];
+            const double val = D.cval[bo.x + e];
+            if (idx == pr) {
+                fa->sX[sg.c] = val;
+                fa->sW[sg.c] = e;
+            } else {
+                atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
+            }
+            if (e == fa->sCnt[sg.c] - 1) {
+                fa->sK0i[sg.c] = idx;
+                fa->sK0v[sg.c] = val;
+            }
+        }
+    }
+    wave_mem_sync();
+    int newlen = -1;
+    double xrj = 0.0;
+    bool tiny = false;
+    if (lane < rnz1) {
+        const int w = fa->sW[lane];
+        DEV_CHECK(S, w >= 0);
+        xrj = fa->sX[lane];
+        newlen = L.cl - 1;
+        if (w >= 0 && w != newlen) {
+            D.cidx[L.cb + w] = fa->sK0i[lane];
+            D.cval[L.cb + w] = fa->sK0v[lane];
+        }
+        const double cmx = __longlong_as_double((long long)fa->sMax[lane]);
+        fa->sMax[lane] = 0ull;
+        D.clen[L.j] = newlen;
+        D.colmax[L.j] = cmx;
+        tiny = cmx == 0.0 || cmx < D.abstol;
+    }
+    const bool ku = lane < rnz1 && fabs(xrj) > D.droptol;
+    const unsigned long long kub = __ballot(ku);
+    int uused = sm->uused;
+    if (ku) {
+        const int d = uused + wave_prefix_count(kub);
+        D.uidx[d] = L.j;
+        D.uval[d] = xrj;
+    }
+    uused += __popcll(kub);
+    const unsigned long long tinyb = __ballot(tiny);
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2);
+    if (lane == 0) {
+        const int rank = sm->rank;
+        D.ubeg[rank + 1] = uused;
+        D.lbeg[rank + 1] = sm->lused; // empty column in L
+        sm->uused = uused;
+        if (mn < sm->min_colnz) sm->min_colnz = mn;
+        if (tinyb) sm->flag_small = 1;
+        D.colmax[pc] = pivot;
+        D.clen[pc] = 0;
+        D.rlen[pr] = 0;
+        sm->kinds[1]++;
+        sm->nfast[1]++;
+    }
+    wave_mem_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pivot loop of one matrix on one wave: factorize_bump (factorize_bump.rs:12-49) + pivot() (pivot.rs:48-112)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
+{
+    const DevGP D(&Ds[blockIdx.x]);
+    Scalars *S = D.s;
+    const int lane = lane_id();
+    const int m = D.m;
+
+    if (S->status != ST_RUNNING) return; // finished or failed in an earlier launch (batch relaunch)
+    Fast *fa = &sm->fa;
+    if (lane == 0) {
+        sm->rank = S->rank;
+        sm->rankdef = S->rankdef;
+        sm->min_colnz = S->min_colnz;
+        sm->min_rownz = S->min_rownz;
+        sm->cused = S->cused;
+        sm->rused = S->rused;
+        sm->lused = S->lused;
+        sm->uused = S->uused;
+        sm->pr = S->pivot_row;
+        sm->pc = S->pivot_col;
+        sm->exit_code = 0;
+        sm->need = 0;
+        sm->nsearch = 0;
+        sm->flops = 0;
+        sm->nexpand = 0;
+        sm->d3 = 0;
+        sm->stop_at = stop_at;
+        sm->flag_small = 0;
+        fa->kind = 0;
+        for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
+        sm->nfast[0] = sm->nfast[1] = 0;
+        g_pivot_err = 0;
+        g_pivot_err_line = 0;
+    }
+    sm->swork[lane] = 0.0;
+    if (lane < 16) sm->wmax[lane] = 0ull;
+    fa->zw[lane] = 0ull; // WV_ZW == 64
+    fa->sMax[lane] = 0ull;
+    for (int k = lane; k < WV_WCAP; k += 64) fa->W[k] = 0.0;
+    wave_mem_sync();
+
+    WvLines L;
+    for (;;) {
+        // ---- loop head: done / stop / error?
+        int head_exit = 0;
+        if (g_pivot_err) head_exit = ST_ERROR;
+        else if (sm->rank + sm->rankdef >= m) head_exit = ST_DONE;
+        else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) head_exit = ST_STOPPED;
+        const bool need_search = sm->pc < 0;
+        WAVE_LOCKSTEP();
+        if (head_exit) {
+            if (lane == 0) sm->exit_code = head_exit;
+            break;
+        }
+        // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
+        bool handled = false;
+        if (need_search) {
+            if (D.search_rows == 0 && !D.no_fast) handled = wv_search(D, sm, L);
+            if (!handled) {
+                if (D.search_rows == 0) markowitz_wave(D, sm);
+                else if (lane == 0) markowitz_serial(D, sm);
+                wave_mem_sync();
+            }
+        }
+        if (!handled) {
+            if (lane == 0) setup_pivot_general(D, sm);
+            wave_mem_sync();
+        }
+        const int pr = sm->pr, pc = sm->pc;
+        const int exit_code = sm->exit_code;
+        const int nz_col = sm->nzc, nz_row = sm->nzr;
+        const int kind = fa->kind;
+        WAVE_LOCKSTEP();
+        if (pc < 0) { // no pivot found: the reference asserts (factorize_bump.rs:22)
+            if (lane == 0) {
+                DEV_CHECK(S, false);
+                sm->exit_code = ST_ERROR;
+            }
+            break;
+        }
+        if (pr < 0) { // eliminate empty column without choosing a pivot (factorize_bump.rs:24-33)
+            if (lane == 0) {
+                list_remove1(D.cflink, D.cblink, pc);
+                sm->pc = -1;
+                sm->rankdef++;
+                sm->kinds[5]++;
+            }
+            wave_mem_sync();
+            continue;
+        }
+        // ---- pivot(): the room check of pivot.rs:70-81 was made by the search; dispatch (:84-94)
+        if (exit_code) break;
+        bool ok = true;
+        if (kind == 1) wv_small(D, sm, L, pr, pc, nz_col, nz_row);
+        else if (kind == 2) wv_scol(D, sm, L, pr, pc, nz_row);
+        else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
+        else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
+        else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
+        else ok = pivot_general(D, sm, nz_col - 1 <= 64);
+        if (!ok) break; // exit_code set, pivot stays pending
+        // ---- remove columns whose maximum dropped below abstol (pivot.rs:98-106), record the pivot
+        if (lane == 0) {
+            const int rank = sm->rank;
+            if (sm->flag_small && nz_row > 1) {
+                for (int pos = D.ubeg[rank]; pos < D.ubeg[rank + 1]; pos++) {
+                    const int j = D.uidx[pos];
+                    if (D.colmax[j] == 0.0 || D.colmax[j] < D.abstol) remove_col_serial(D, sm, j);
+                }
+            }
+            sm->flops += (long long)(nz_col - 1) * (long long)(nz_row - 1);
+            D.pinv[pr] = rank;
+            D.qinv[pc] = rank;
+            D.prow[rank] = pr;
+            D.pcol[rank] = pc;
+            sm->pc = -1;
+            sm->pr = -1;
+            sm->rank = rank + 1;
+        }
+        wave_mem_sync();
+    }
+    wave_mem_sync();
+    if (lane == 0) {
+        S->rank = sm->rank;
+        S->rankdef = sm->rankdef;
+        S->min_colnz = sm->min_colnz;
+        S->min_rownz = sm->min_rownz;
+        S->cused = sm->cused;
+        S->rused = sm->rused;
+        S->lused = sm->lused;
+        S->uused = sm->uused;
+        S->pivot_row = sm->pr;
+        S->pivot_col = sm->pc;
+        S->need = sm->need;
+        S->nsearch_pivot += sm->nsearch;
+        S->factor_flops += sm->flops;
+        S->nexpand += sm->nexpand;
+        S->d3_hits += sm->d3;
+        for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
+        S->nfast[0] += sm->nfast[0];
+        S->nfast[1] += sm->nfast[1];
+        if (sm->exit_code == ST_ERROR && g_pivot_err_line) set_error(S, ST_ERROR, g_pivot_err_line);
+        if (S->status == ST_RUNNING) S->status = sm->exit_code;
+    }
+}
+
+#ifndef BLU_WAVE_OCC
+#define BLU_WAVE_OCC 4 // waves per SIMD the register budget is set for
+#endif
+__global__ void __launch_bounds__(64) BLU_WAVES_PER_EU(BLU_WAVE_OCC, BLU_WAVE_OCC) k_pivot_loop_wave(DevLU *Ds, int stop_at)
+{
+    __shared__ Sm smem;
+    pivot_loop_wave(Ds, stop_at, &smem);
+}

@@ -1,0 +1,48 @@
+// k_pivot_wave_types.h -- LDS working set of the one-wave-per-matrix pivot kernel (k_pivot_wave.hip).
+// (no include guard: included inside the pv_wave namespace of k_pivot.hip)
+//
+// One wave = one matrix, so nothing here is shared between waves and no workgroup barrier is needed; the
+// whole struct is sized so that many workgroups of one wave each share a CU (LDS is the limit next to
+// registers).  "slot" = position in the pivot row (columns, slot 0 = pivot column) or in the pivot
+// column (rows, slot 0 = pivot row) after the swap of pivot.rs:169-185; a line update handles slots
+// 1..n, which live in lanes 0..n-1.
+#undef WV_SLOTS
+#undef WV_HBITS
+#undef WV_HASH
+#undef WV_ZW
+#undef WV_TMAX
+#undef WV_WCAP
+#undef WV_STG
+#undef KCMAX
+#define WV_SLOTS 64   // lines per phase: pivot rows and pivot columns of <= 64 entries (one lane each)
+#define WV_HBITS 7
+#define WV_HASH 128   // hash slots: <= 64 keys, at most half full
+#define WV_ZW 64      // zero-words: segment-head bits of a flattened pass / key groups of a list move
+#define WV_TMAX (64 * WV_ZW) // entries of all lines of one flattened phase
+#define WV_WCAP 128   // old values of the entries being updated, columns of one group x pivot-column positions
+#define WV_STG 128    // entries of the candidate columns of one search
+#define KCMAX 4       // candidate columns of a search (maxsearch <= KCMAX)
+
+struct Fast {
+    int kind;  // 0 general paths, 1 pivot_small, 2 pivot_singleton_col
+    int where, anycancel, ncand;
+    int cJ[KCMAX], cNz[KCMAX], cB[KCMAX], cL[KCMAX], cOff[KCMAX + 1];
+    double cMx[KCMAX];
+    unsigned long long hsh[WV_HASH]; // (key << 32) | value, ~0 = empty
+    unsigned long long zw[WV_ZW];    // all zero between uses
+    int2 sBO[WV_SLOTS];              // line of slot s: {begin, offset of its first entry in the flattened index space}
+    int sCnt[WV_SLOTS];              // entries kept so far (running, across the passes of a line)
+    int sSeg[WV_SLOTS];              // (ballot prefix at the line's first lane of this pass) - (kept before this pass)
+    int sW[WV_SLOTS];                // rank of the pivot-row entry among the kept entries
+    double sX[WV_SLOTS];             // pivot-row entry xrj, then the multiplier xrj / pivot
+    unsigned long long sMax[WV_SLOTS]; // bit pattern of the line's new maximum, zero between uses
+    double sK0v[WV_SLOTS];           // first kept entry of the line (it goes where the pivot-row entry was, pivot.rs:261)
+    int sK0i[WV_SLOTS];
+    unsigned long long sM[WV_SLOTS]; // cancellation mask of the column (bit p = position p+1 of the pivot column, pivot.rs:645-664)
+    int sDst[WV_SLOTS];              // where the appended part of the line begins
+    int sNew[WV_SLOTS];              // entries appended
+    int tJ[WV_SLOTS + 1];            // pivot row, slot order
+    int pI[WV_SLOTS + 1];            // pivot column, slot order
+    double pV[WV_SLOTS + 1];
+    double W[WV_WCAP];               // all zero between pivots
+};

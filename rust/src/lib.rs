@@ -310,6 +310,10 @@ impl BLU {
 
     /// `BLU::solve_sparse` (`blu.rs:207-225`): the solution is left in `self.lhs` / `self.ilhs[..self.nzlhs]`.
     pub fn solve_sparse(&mut self, nzrhs: LUInt, irhs: &[usize], xrhs: &[f64], trans: char) -> Result<(), Status> {
+        // the C side reads irhs[0..nzrhs) and xrhs[0..nzrhs): never hand it a count beyond the slices
+        if nzrhs < 0 || nzrhs as usize > irhs.len() || nzrhs as usize > xrhs.len() {
+            return Err(Status::ErrorInvalidArgument);
+        }
         self.clear_lhs();
         let mut nz: i64 = 0;
         let code = unsafe {
@@ -325,6 +329,11 @@ impl BLU {
     /// `BLU::solve_for_update` (`blu.rs:257-288`).  With `want_solution != 0` the solution is left in
     /// `self.lhs` / `self.ilhs[..self.nzlhs]`; otherwise only the update is prepared.
     pub fn solve_for_update(&mut self, nzrhs: usize, irhs: &[usize], xrhs: Option<&[f64]>, trans: char, want_solution: LUInt) -> Result<(), Status> {
+        // the C side reads irhs[0..nzrhs) / xrhs[0..nzrhs), and irhs[0] for a transposed solve even when nzrhs == 0
+        let transposed = trans == 't' || trans == 'T';
+        if nzrhs > irhs.len() || xrhs.map_or(false, |x| nzrhs > x.len()) || (transposed && irhs.is_empty()) {
+            return Err(Status::ErrorInvalidArgument);
+        }
         self.clear_lhs();
         let xp = xrhs.map(|x| x.as_ptr()).unwrap_or(std::ptr::null());
         let mut nz: i64 = 0;

@@ -26,5 +26,9 @@ for rep in range(3):
     assert all(s == 0 for s in st), st
     F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs); lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
     tp = hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP)
-    print("B=%d block=%d rep%d: %.3f s  %.1f Mnnz/s  pivot-kernel %.3f s (%d launches) -> %.1f GB/s alg" %
-          (B, block, rep, el, nnz / el / 1e6, tp, hs[0].stat(K.STAT_DEV_RELAUNCHES), (32 * F + 32 * lu) / tp / 1e9), flush=True)
+    ph = [hs[0].stat(k) for k in (44, 45, 46, 47)]
+    print("B=%d block=%d kernel=%s rep%d: %.3f s  %.1f Mnnz/s  pivot-kernel %.3f s (%d launches) -> %.1f GB/s alg (%.2f%% of 8 TB/s); "
+          "prep %.3f setup %.3f finish %.3f stats %.3f s; fast small/scol %d/%d of %d/%d" %
+          (B, block, os.environ.get("BLU_PIVOT_KERNEL", "default"), rep, el, nnz / el / 1e6, tp, hs[0].stat(K.STAT_DEV_RELAUNCHES),
+           (32 * F + 32 * lu) / tp / 1e9, (32 * F + 32 * lu) / tp / 1e9 / 80.0, ph[0], ph[1], ph[2], ph[3],
+           hs[0].stat(110), hs[0].stat(111), hs[0].stat(54), hs[0].stat(52)), flush=True)
