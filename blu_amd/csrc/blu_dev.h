@@ -68,7 +68,7 @@ struct Scalars {
     long long ngarbage;
     long long d3_hits;    // cancellations at pivot-column position >= 32 (reference defect D3 would diverge)
     long long npivot_kind[6];  // counters: 0 singleton row, 1 singleton col, 2 doubleton, 3 small, 4 any, 5 empty col
-    long long nfast[2];        // of those, taken by the flattened paths of k_pivot_loop_wave: small, singleton col
+    long long nfast[4];        // k_pivot_loop_wave: pivots taken by its flattened paths (small, singleton col), searches handed over by the previous pivot
     double min_pivot, max_pivot;
     double onenorm, infnorm;
     double norm_l, norm_u, normest_l_inv, normest_u_inv, condest_l, condest_u, residual_test;

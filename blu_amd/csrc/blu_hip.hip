@@ -452,7 +452,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 54: return (double)s.npivot_kind[3];
     case 55: return (double)s.npivot_kind[4];
     case 56: return (double)s.npivot_kind[5];
-    case 110: case 111: return (double)s.nfast[key - 110]; // pivots taken by the flattened paths of k_pivot_loop_wave
+    case 110: case 111: case 116: case 117: return (double)s.nfast[key < 116 ? key - 110 : key - 114]; // pivots taken by the flattened paths of k_pivot_loop_wave
     case 112: return (double)s.cused;  // entries of the column / row arena handed out (bump pointers)
     case 113: return (double)s.rused;
     case 114: return (double)h->D.carena_cap;

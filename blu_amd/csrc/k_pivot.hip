@@ -96,7 +96,7 @@ struct alignas(16) Sm {
     double pivot, other_value;
     long long nsearch, flops, nexpand, d3;
     long long kinds[6];
-    long long nfast[2];
+    long long nfast[4];
     int sh[40];
     long long shl[20];
     unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses

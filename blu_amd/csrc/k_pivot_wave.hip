@@ -104,13 +104,16 @@ __device__ __forceinline__ int wv_lane_of(const Fast *fa, int e, bool want, int 
     const int s = wv_hfind(fa, e);
     return s < 0 ? -1 : (s == 0 ? n : s - 1);
 }
-__device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int key, bool act, bool isgone, int fl, int bl, int n, int big)
+// t_before: the tail of the lane's new list as it was before this batch (m + key = the list was empty)
+__device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int key, bool act, bool isgone, int fl, int bl, int n, int big,
+                                            int &t_before)
 {
     const int lane = lane_id();
     const int m = D.m;
     const bool unl = act || isgone;
     int t = 0;
     if (act) t = D.cblink[m + key]; // tail of the new list as it is BEFORE the unlinks
+    t_before = t;
     // lanes of equal key meet in an LDS word indexed by the key (all-zero between calls); large keys by ballots
     unsigned long long mygrp = 0ull;
     if (!__ballot(act && key >= WV_ZW)) {
@@ -176,136 +179,14 @@ __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int
     return minall;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Search (markowitz.rs:34-123, search_rows == 0) + pivot set-up.  Returns false if the shape is outside what this
-// path handles (nothing modified: the caller runs markowitz_wave).  On true: sm->pr / sm->pc are set (pr < 0: an
-// empty column was chosen; both < 0: error raised), fa->kind says which pivot function runs, L holds the lines.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
+// Second half of the search: room in L and U, the kind of pivot, and -- for the two flattened kinds -- the pivot row
+// (and column) in slot order with the metadata of every line they touch.  pv1 = the pivot value of a column singleton.
+__device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, int pc, int pr, int nzc, int pcb, int nzr, int prb, int where,
+                                          int found_nz, int nsearched, double pv1)
 {
     const int lane = lane_id();
-    const int m = D.m;
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
-    const int K = D.maxsearch;
-    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost * 256 + position must fit 64 bits)
-    const int nz0 = sm->min_colnz;
-    if (nz0 < 1) return false;
-    // heads of list 0 (lane 0) and of lists nz0 .. nz0+62 (lanes 1..63), one gather
-    const int kk = lane == 0 ? 0 : nz0 + lane - 1;
-    const int h = kk <= m ? D.cflink[m + kk] : m + kk;
-    const int h0 = __builtin_amdgcn_readlane(h, 0);
-    if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
-        if (lane == 0) {
-            sm->pc = h0;
-            sm->pr = -1;
-            fa->kind = 0;
-        }
-        wave_mem_sync();
-        return true;
-    }
-    unsigned long long ne = __ballot(lane >= 1 && kk <= m && h != m + kk);
-    if (!ne) return false; // (a long stretch of empty lists: the general search skips them 64 at a time)
-    const int left = m - sm->rank - sm->rankdef; // every active column is in a count list; list 0 is empty
-    const int nsearched = left < K ? left : K;
-
-    int pc, pr, nzc, pcb, nzr, where, found_nz;
-    if (nz0 == 1 && (ne & 2ull)) {
-        // ---- column singleton: its one entry costs 0 and no later candidate can be strictly cheaper
-        // (markowitz.rs:105); the reference still looks at maxsearch columns, which only shows in nsearch_pivot
-        pc = __builtin_amdgcn_readlane(h, 1);
-        pcb = D.cbeg[pc];
-        const int cl = D.clen[pc];
-        const double cmx = D.colmax[pc];
-        if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false; // (the general search raises the error)
-        pr = D.cidx[pcb];
-        const double x = fabs(D.cval[pcb]);
-        const double tol = fmax(D.abstol, D.reltol * cmx);
-        if (x == 0.0 || x < tol) return false;
-        nzc = 1;
-        nzr = D.rlen[pr];
-        where = 0;
-        found_nz = 1;
-    } else {
-        // ---- walk the lists to the first K columns (dependent loads: link + metadata of one column at a time)
-        int ncand = 0, total = 0;
-        bool bad = false;
-        found_nz = -1;
-        while (ne && ncand < K && !bad) {
-            const int b = __ffsll((long long)ne) - 1;
-            ne &= ne - 1;
-            int j = __builtin_amdgcn_readlane(h, b);
-            const int znz = nz0 + b - 1;
-            int guard = 0;
-            while (j < m && ncand < K) {
-                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
-                const double cmx = D.colmax[j];
-                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
-                    bad = true;
-                    break;
-                }
-                if (lane == 0) {
-                    fa->cJ[ncand] = j;
-                    fa->cNz[ncand] = znz;
-                    fa->cB[ncand] = cb;
-                    fa->cL[ncand] = cl;
-                    fa->cMx[ncand] = cmx;
-                    fa->cOff[ncand] = total;
-                }
-                if (found_nz < 0) found_nz = znz;
-                total += cl;
-                ncand++;
-                j = fl;
-            }
-        }
-        if (bad) return false; // reference: assert / D2; the general search raises it
-        if (ncand < nsearched) return false; // more columns exist in lists beyond nz0+62
-        if (total > WV_STG) return false;
-        if (lane == 0) fa->cOff[ncand] = total;
-        wave_mem_sync();
-        const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
-                  off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
-        // ---- all candidate entries in one flattened pass (two for > 64): cost of every eligible entry; the
-        // reference's sequential strict-< scan is the lexicographic minimum over (cost, flat position)
-        const long long BIG = 0x7fffffffffffffffLL;
-        long long mcb = BIG;
-        int idx0 = 0, idx1 = 0, rl0 = 0, rl1 = 0;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int f = u * 64 + lane;
-            if (f < total) {
-                const int c = (f >= off1) + (f >= off2) + (f >= off3);
-                const int pos = fa->cB[c] + f - fa->cOff[c];
-                const int idx = D.cidx[pos];
-                const double val = D.cval[pos];
-                const int rl = D.rlen[idx];
-                const double tol = fmax(D.abstol, D.reltol * fa->cMx[c]);
-                const double x = fabs(val);
-                if (!(x == 0.0 || x < tol)) {
-                    const long long key = (long long)(fa->cNz[c] - 1) * (long long)(rl - 1) * 256LL + (long long)f;
-                    if (key < mcb) mcb = key;
-                }
-                if (u == 0) {
-                    idx0 = idx;
-                    rl0 = rl;
-                } else {
-                    idx1 = idx;
-                    rl1 = rl;
-                }
-            }
-        }
-        const long long best = wave_min_ll(mcb);
-        if (best == BIG) return false; // no eligible entry: cannot happen; the general search raises it
-        const int fsel = (int)(best & 255LL);
-        const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
-        pc = fa->cJ[csel];
-        nzc = fa->cL[csel];
-        pcb = fa->cB[csel];
-        where = fsel - fa->cOff[csel];
-        pr = __builtin_amdgcn_readlane(fsel < 64 ? idx0 : idx1, fsel & 63);
-        nzr = __builtin_amdgcn_readlane(fsel < 64 ? rl0 : rl1, fsel & 63);
-    }
-    const int prb = D.rbeg[pr];
     int exit_code = 0, need = 0;
     // room in L and U (pivot.rs:70-81)
     if (sm->lused + (nzc - 1) > D.lcap) {
@@ -374,6 +255,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         fa->pI[slot] = ci;
         fa->pV[slot] = cv;
     }
+    if (kind == 2 && lane == 0) fa->pV[0] = pv1;
     wave_mem_sync();
     L.j = lane <= rnz1 ? fa->tJ[lane < rnz1 ? lane + 1 : 0] : -1; // lane rnz1: the pivot column
     L.cb = L.cl = L.cap = L.fl = L.bl = 0;
@@ -424,6 +306,156 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Search (markowitz.rs:34-123, search_rows == 0) + pivot set-up.  Returns false if the shape is outside what this
+// path handles (nothing modified: the caller runs markowitz_wave).  On true: sm->pr / sm->pc are set (pr < 0: an
+// empty column was chosen; both < 0: error raised), fa->kind says which pivot function runs, L holds the lines.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Scalars *S = D.s;
+    Fast *fa = &sm->fa;
+    const int K = D.maxsearch;
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost * 256 + position must fit 64 bits)
+    const int nz0 = sm->min_colnz;
+    if (nz0 < 1) return false;
+    const bool handed = fa->nxValid != 0;
+    WAVE_LOCKSTEP();
+    if (handed) {
+        // ---- the previous pivot (a column singleton) left the next one: see wv_scol
+        if (lane == 0) {
+            fa->nxValid = 0;
+            sm->nfast[2]++;
+        }
+        const int pc = fa->nxPc, pr = fa->nxPr;
+        const int left = m - sm->rank - sm->rankdef;
+        return wv_layout(D, sm, L, pc, pr, 1, fa->nxPcb, D.rlen[pr], D.rbeg[pr], 0, 1, left < K ? left : K, fa->nxVal);
+    }
+    // heads of list 0 (lane 0) and of lists nz0 .. nz0+62 (lanes 1..63), one gather
+    const int kk = lane == 0 ? 0 : nz0 + lane - 1;
+    const int h = kk <= m ? D.cflink[m + kk] : m + kk;
+    const int h0 = __builtin_amdgcn_readlane(h, 0);
+    if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
+        if (lane == 0) {
+            sm->pc = h0;
+            sm->pr = -1;
+            fa->kind = 0;
+        }
+        wave_mem_sync();
+        return true;
+    }
+    unsigned long long ne = __ballot(lane >= 1 && kk <= m && h != m + kk);
+    if (!ne) return false; // (a long stretch of empty lists: the general search skips them 64 at a time)
+    const int left = m - sm->rank - sm->rankdef; // every active column is in a count list; list 0 is empty
+    const int nsearched = left < K ? left : K;
+
+    int pc, pr, nzc, pcb, nzr, prb, where, found_nz;
+    double pv1 = 0.0;
+    if (nz0 == 1 && (ne & 2ull)) {
+        // ---- column singleton: its one entry costs 0 and no later candidate can be strictly cheaper
+        // (markowitz.rs:105); the reference still looks at maxsearch columns, which only shows in nsearch_pivot
+        pc = __builtin_amdgcn_readlane(h, 1);
+        pcb = D.cbeg[pc];
+        const int cl = D.clen[pc];
+        const double cmx = D.colmax[pc];
+        if (cl != 1 || cmx == 0.0 || !(cmx >= D.abstol)) return false; // (the general search raises the error)
+        pr = D.cidx[pcb];
+        pv1 = D.cval[pcb];
+        const double x = fabs(pv1);
+        const double tol = fmax(D.abstol, D.reltol * cmx);
+        if (x == 0.0 || x < tol) return false;
+        nzc = 1;
+        nzr = D.rlen[pr];
+        prb = D.rbeg[pr];
+        where = 0;
+        found_nz = 1;
+    } else {
+        // ---- walk the lists to the first K columns (dependent loads: link + metadata of one column at a time)
+        int ncand = 0, total = 0;
+        bool bad = false;
+        found_nz = -1;
+        while (ne && ncand < K && !bad) {
+            const int b = __ffsll((long long)ne) - 1;
+            ne &= ne - 1;
+            int j = __builtin_amdgcn_readlane(h, b);
+            const int znz = nz0 + b - 1;
+            int guard = 0;
+            while (j < m && ncand < K) {
+                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
+                const double cmx = D.colmax[j];
+                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
+                    bad = true;
+                    break;
+                }
+                if (lane == 0) {
+                    fa->cJ[ncand] = j;
+                    fa->cNz[ncand] = znz;
+                    fa->cB[ncand] = cb;
+                    fa->cL[ncand] = cl;
+                    fa->cMx[ncand] = cmx;
+                    fa->cOff[ncand] = total;
+                }
+                if (found_nz < 0) found_nz = znz;
+                total += cl;
+                ncand++;
+                j = fl;
+            }
+        }
+        if (bad) return false; // reference: assert / D2; the general search raises it
+        if (ncand < nsearched) return false; // more columns exist in lists beyond nz0+62
+        if (total > WV_STG) return false;
+        if (lane == 0) fa->cOff[ncand] = total;
+        wave_mem_sync();
+        const int off1 = ncand > 1 ? fa->cOff[1] : 0x7fffffff, off2 = ncand > 2 ? fa->cOff[2] : 0x7fffffff,
+                  off3 = ncand > 3 ? fa->cOff[3] : 0x7fffffff;
+        // ---- all candidate entries in one flattened pass (two for > 64): cost of every eligible entry; the
+        // reference's sequential strict-< scan is the lexicographic minimum over (cost, flat position)
+        const long long BIG = 0x7fffffffffffffffLL;
+        long long mcb = BIG;
+        int idx0 = 0, idx1 = 0, rl0 = 0, rl1 = 0, rb0 = 0, rb1 = 0;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int f = u * 64 + lane;
+            if (f < total) {
+                const int c = (f >= off1) + (f >= off2) + (f >= off3);
+                const int pos = fa->cB[c] + f - fa->cOff[c];
+                const int idx = D.cidx[pos];
+                const double val = D.cval[pos];
+                const int rl = D.rlen[idx], rbg = D.rbeg[idx]; // (the winner's row begin comes with its length: one round trip less)
+                const double tol = fmax(D.abstol, D.reltol * fa->cMx[c]);
+                const double x = fabs(val);
+                if (!(x == 0.0 || x < tol)) {
+                    const long long key = (long long)(fa->cNz[c] - 1) * (long long)(rl - 1) * 256LL + (long long)f;
+                    if (key < mcb) mcb = key;
+                }
+                if (u == 0) {
+                    idx0 = idx;
+                    rl0 = rl;
+                    rb0 = rbg;
+                } else {
+                    idx1 = idx;
+                    rl1 = rl;
+                    rb1 = rbg;
+                }
+            }
+        }
+        const long long best = wave_min_ll(mcb);
+        if (best == BIG) return false; // no eligible entry: cannot happen; the general search raises it
+        const int fsel = (int)(best & 255LL);
+        const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
+        pc = fa->cJ[csel];
+        nzc = fa->cL[csel];
+        pcb = fa->cB[csel];
+        where = fsel - fa->cOff[csel];
+        pr = __builtin_amdgcn_readlane(fsel < 64 ? idx0 : idx1, fsel & 63);
+        nzr = __builtin_amdgcn_readlane(fsel < 64 ? rl0 : rl1, fsel & 63);
+        prb = __builtin_amdgcn_readlane(fsel < 64 ? rb0 : rb1, fsel & 63);
+    }
+    return wv_layout(D, sm, L, pc, pr, nzc, pcb, nzr, prb, where, found_nz, nsearched, pv1);
+}
+
 // Segment bookkeeping of a flattened pass.  `hw` = head bits of this pass, `cbv` = (slot of the last line begun
 // before this pass); returns this lane's slot and tells whether it is the first / last lane of its line IN THIS PASS.
 struct WvSeg {
@@ -439,6 +471,42 @@ __device__ __forceinline__ WvSeg wv_segment(unsigned long long hw, int cbv, bool
     s.head = valid && (own || lane == 0);
     s.tail = valid && (lane == 63 || lastflat || (((hw >> 1) >> lane) & 1ull));
     return s;
+}
+
+// One pass of a flattened phase, loads issued: which line each lane is in, the entry it holds.  The passes are
+// software-pipelined -- pass k+1 is fetched before pass k is worked on -- because a wave alone on its matrix has
+// nothing else to hide a memory round trip behind, and a small pivot has ~16 such passes.  (The in-place stores of
+// pass k go to positions below the entries pass k read, so they never touch what pass k+1 has already loaded.)
+struct WvPass {
+    WvSeg sg;
+    bool valid;
+    int2 bo;
+    int e, idx;
+    double val;
+};
+template <bool VALUES>
+__device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idxarr, int k, int T, int f0, int &cbv)
+{
+    const int lane = lane_id();
+    WvPass P;
+    const unsigned long long hw = fa->zw[k];
+    WAVE_LOCKSTEP();
+    if (lane == 0) fa->zw[k] = 0ull;
+    const int f = k * 64 + lane;
+    P.valid = f < T;
+    P.sg = wv_segment(hw, cbv, P.valid, f == T - 1);
+    cbv += __popcll(hw);
+    P.bo = make_int2(0, 0);
+    P.e = 0;
+    P.idx = -1;
+    P.val = 0.0;
+    if (P.valid) {
+        P.bo = fa->sBO[P.sg.c];
+        P.e = f + f0 - P.bo.y;
+        P.idx = idxarr[P.bo.x + P.e];
+        if (VALUES) P.val = D.cval[P.bo.x + P.e];
+    }
+    return P;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,23 +565,15 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         // ---- pass A: every entry of the group's columns.  Entries whose row is in the pivot column leave the
         // column (their value goes to W); the others are compressed in place, keeping their order
         int cbv = c0 - 1;
+        WvPass nx = wv_fetch<true>(D, fa, D.cidx, 0, Tg, f0, cbv);
         for (int k = 0; k * 64 < Tg; k++) {
-            const unsigned long long hw = fa->zw[k];
-            WAVE_LOCKSTEP();
-            if (lane == 0) fa->zw[k] = 0ull;
-            const int f = k * 64 + lane;
-            const bool valid = f < Tg;
-            const WvSeg sg = wv_segment(hw, cbv, valid, f == Tg - 1);
-            cbv += __popcll(hw);
-            int2 bo = make_int2(0, 0);
-            int e = 0, idx = -1;
-            double val = 0.0;
-            if (valid) {
-                bo = fa->sBO[sg.c];
-                e = f + f0 - bo.y;
-                idx = D.cidx[bo.x + e];
-                val = D.cval[bo.x + e];
-            }
+            const WvPass P = nx;
+            if ((k + 1) * 64 < Tg) nx = wv_fetch<true>(D, fa, D.cidx, k + 1, Tg, f0, cbv);
+            const WvSeg sg = P.sg;
+            const bool valid = P.valid;
+            const int2 bo = P.bo;
+            const int idx = P.idx;
+            const double val = P.val;
             const int p = valid ? wv_hfind(fa, idx) : -1;
             const bool hit = valid && p >= 0;
             const bool keep = valid && !hit;
@@ -656,21 +716,13 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     wave_mem_sync();
     {
         int cbv = -1;
+        WvPass nx = wv_fetch<false>(D, fa, D.ridx, 0, Tr, 0, cbv);
         for (int k = 0; k * 64 < Tr; k++) {
-            const unsigned long long hw = fa->zw[k];
-            WAVE_LOCKSTEP();
-            if (lane == 0) fa->zw[k] = 0ull;
-            const int f = k * 64 + lane;
-            const bool valid = f < Tr;
-            const WvSeg sg = wv_segment(hw, cbv, valid, f == Tr - 1);
-            cbv += __popcll(hw);
-            int2 bo = make_int2(0, 0);
-            int e = 0, j = -1;
-            if (valid) {
-                bo = fa->sBO[sg.c];
-                e = f - bo.y;
-                j = D.ridx[bo.x + e];
-            }
+            const WvPass P = nx;
+            if ((k + 1) * 64 < Tr) nx = wv_fetch<false>(D, fa, D.ridx, k + 1, Tr, 0, cbv);
+            const WvSeg sg = P.sg;
+            const bool valid = P.valid;
+            const int j = P.idx;
             const bool keep = valid && wv_hfind(fa, j) < 0; // overlap with the pivot row leaves, pivot column included
             const unsigned long long kb = __ballot(keep);
             const int pre = wave_prefix_count(kb);
@@ -678,7 +730,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             wave_mem_sync();
             const int t = valid ? pre - fa->sSeg[sg.c] : 0;
             if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
-            if (keep && t != e) D.ridx[bo.x + t] = j;
+            if (keep && t != P.e) D.ridx[P.bo.x + t] = j;
         }
     }
     wave_mem_sync();
@@ -759,7 +811,8 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
 
     // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
     // pivot-row order; the pivot column leaves
-    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2);
+    int t_before;
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
 
     // ---- cleanup (pivot.rs:792-800)
     if (lane == 0) {
@@ -794,7 +847,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
     const int rnz1 = nz_row - 1;
-    const double pivot = D.cval[sm->pcb];
+    const double pivot = fa->pV[0]; // (the search left it there)
     DEV_CHECK(S, pivot != 0.0);
 
     wv_hclear(fa);
@@ -806,6 +859,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
         fa->sBO[lane] = make_int2(L.cb, coff);
         fa->sCnt[lane] = L.cl;
         fa->sW[lane] = -1;
+        fa->sNew[lane] = -1;
         atomicOr(&fa->zw[coff >> 6], 1ull << (coff & 63));
     }
     wave_mem_sync();
@@ -828,6 +882,10 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
                 fa->sW[sg.c] = e;
             } else {
                 atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
+                if (fa->sCnt[sg.c] == 2) { // the entry a column of two keeps: if that column is the next pivot, this is its pivot
+                    fa->sNew[sg.c] = idx;
+                    fa->sM[sg.c] = (unsigned long long)__double_as_longlong(val);
+                }
             }
             if (e == fa->sCnt[sg.c] - 1) {
                 fa->sK0i[sg.c] = idx;
@@ -864,7 +922,39 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     }
     uused += __popcll(kub);
     const unsigned long long tinyb = __ballot(tiny);
-    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2);
+    int t_before;
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
+    // ---- hand-over to the next search.  A chain of column singletons (the triangular part of an LP basis: half of all
+    // pivots) uncovers one singleton per pivot: if the count-1 list held nothing but this pivot column, its head is now the
+    // first column this pivot left with one entry -- and that entry passed through the lanes above.  The next search
+    // then starts at the pivot row (6 dependent round trips less: list heads, column, entry).
+    {
+        // (the pivot column itself was the only member of the count-1 list: both its links were the list head)
+        const bool only_pc = __builtin_amdgcn_readlane(L.fl, rnz1) == D.m + 1 && __builtin_amdgcn_readlane(L.bl, rnz1) == D.m + 1;
+        const bool cand = lane < rnz1 && newlen == 1 && only_pc;
+        const unsigned long long candb = __ballot(cand);
+        const unsigned long long zerob = __ballot(lane < rnz1 && newlen == 0);
+#ifdef WV_DEBUG_HAND
+        const int dfl = __builtin_amdgcn_readlane(L.fl, rnz1), dbl = __builtin_amdgcn_readlane(L.bl, rnz1);
+        if (lane == 0 && sm->rank < 40) printf("rank %d pc %d: only_pc %d (fl %d bl %d m+1 %d) candb %llx tinyb %llx zerob %llx\n", sm->rank, pc, (int)only_pc, dfl, dbl, D.m + 1, candb, tinyb, zerob);
+#endif
+        if (candb && !tinyb && !zerob) { // (uniform)
+            const int first = __ffsll((long long)candb) - 1;
+            if (lane == first) {
+                const int oi = fa->sNew[lane];
+                const double ov = __longlong_as_double((long long)fa->sM[lane]);
+                const double x = fabs(ov);
+                const double tol = fmax(D.abstol, D.reltol * x); // (the column's maximum is this entry)
+                if (oi >= 0 && !(x == 0.0 || x < tol)) {
+                    fa->nxPc = L.j;
+                    fa->nxPr = oi;
+                    fa->nxPcb = L.cb;
+                    fa->nxVal = ov;
+                    fa->nxValid = 1;
+                }
+            }
+        }
+    }
     if (lane == 0) {
         const int rank = sm->rank;
         D.ubeg[rank + 1] = uused;
@@ -913,8 +1003,9 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         sm->stop_at = stop_at;
         sm->flag_small = 0;
         fa->kind = 0;
+        fa->nxValid = 0;
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
-        sm->nfast[0] = sm->nfast[1] = 0;
+        sm->nfast[0] = sm->nfast[1] = sm->nfast[2] = sm->nfast[3] = 0;
         g_pivot_err = 0;
         g_pivot_err_line = 0;
     }
@@ -1022,8 +1113,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         S->nexpand += sm->nexpand;
         S->d3_hits += sm->d3;
         for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
-        S->nfast[0] += sm->nfast[0];
-        S->nfast[1] += sm->nfast[1];
+        for (int k = 0; k < 4; k++) S->nfast[k] += sm->nfast[k];
         if (sm->exit_code == ST_ERROR && g_pivot_err_line) set_error(S, ST_ERROR, g_pivot_err_line);
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }

@@ -19,13 +19,16 @@
 #define WV_HASH 128   // hash slots: <= 64 keys, at most half full
 #define WV_ZW 64      // zero-words: segment-head bits of a flattened pass / key groups of a list move
 #define WV_TMAX (64 * WV_ZW) // entries of all lines of one flattened phase
-#define WV_WCAP 128   // old values of the entries being updated, columns of one group x pivot-column positions
+#define WV_WCAP 256   // old values of the entries being updated, columns of one group x pivot-column positions
 #define WV_STG 128    // entries of the candidate columns of one search
 #define KCMAX 4       // candidate columns of a search (maxsearch <= KCMAX)
 
 struct Fast {
     int kind;  // 0 general paths, 1 pivot_small, 2 pivot_singleton_col
     int where, anycancel, ncand;
+    // hand-over from a singleton-column pivot: the next pivot is a column singleton whose one entry that pivot saw
+    int nxValid, nxPc, nxPr, nxPcb;
+    double nxVal;
     int cJ[KCMAX], cNz[KCMAX], cB[KCMAX], cL[KCMAX], cOff[KCMAX + 1];
     double cMx[KCMAX];
     unsigned long long hsh[WV_HASH]; // (key << 32) | value, ~0 = empty

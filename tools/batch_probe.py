@@ -31,4 +31,4 @@ for rep in range(3):
           "prep %.3f setup %.3f finish %.3f stats %.3f s; fast small/scol %d/%d of %d/%d" %
           (B, block, os.environ.get("BLU_PIVOT_KERNEL", "default"), rep, el, nnz / el / 1e6, tp, hs[0].stat(K.STAT_DEV_RELAUNCHES),
            (32 * F + 32 * lu) / tp / 1e9, (32 * F + 32 * lu) / tp / 1e9 / 80.0, ph[0], ph[1], ph[2], ph[3],
-           hs[0].stat(110), hs[0].stat(111), hs[0].stat(54), hs[0].stat(52)), flush=True)
+           hs[0].stat(110), hs[0].stat(111), hs[0].stat(54), hs[0].stat(52)), "handed", hs[0].stat(116), flush=True)
