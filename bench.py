@@ -217,7 +217,9 @@ def rank_main(args, backend=None, device=None):
     stub = backend is not None
     if not stub:
         import blu_amd as backend
-    dist = world > 1
+    # under a launcher (RANK and MASTER_ADDR set) the process group is initialised whatever the world size, so that the
+    # RCCL barrier / MAX / SUM path of shard.py runs at N = 1 too (tests/test_gpu_bench.py does exactly that)
+    dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ and not stub)
     import torch.distributed as td
     if stub:
         dev = device if device is not None else torch.device("cpu")
@@ -230,6 +232,8 @@ def rank_main(args, backend=None, device=None):
         if dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             td.init_process_group("nccl", device_id=dev)
+            if rank == 0:
+                print("process group: %s, world size %d" % (td.get_backend(), td.get_world_size()), file=sys.stderr, flush=True)
 
     c = dict(CONFIGS[args.config])
     n_bases = 8 if args.config == "C4" else world

@@ -335,6 +335,13 @@ class BLU:
         if st != K.OK:
             raise BluError(st)
 
+    def dbg_set_pivot_kernel(self, which):
+        """0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = one wave per matrix, 2 = multi-wave workgroups"""
+        lib().blu_hip_dbg_set_pivot_kernel.argtypes = [C.c_void_p, C.c_int]
+        st = lib().blu_hip_dbg_set_pivot_kernel(self._h, int(which))
+        if st != K.OK:
+            raise BluError(st, "dbg_set_pivot_kernel")
+
     def dbg_set_no_fast(self, on=True):
         """Run the general pivot paths only (k_pivot_fast.hip off): A/B of the two implementations."""
         lib().blu_hip_dbg_set_no_fast.argtypes = [C.c_void_p, C.c_int]

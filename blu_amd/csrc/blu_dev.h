@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <hip/hip_cooperative_groups.h>
 #include <rocprim/warp/warp_reduce.hpp>
+#include <rocprim/warp/warp_scan.hpp>
 
 #define BLU_WAVE 64
 
@@ -293,17 +294,30 @@ __device__ __forceinline__ int wave_sum_i(int v) { return wave_allreduce(v, OpSu
 __device__ __forceinline__ long long wave_min_ll(long long v) { return wave_allreduce(v, OpMinLL()); }
 __device__ __forceinline__ long long wave_sum_ll(long long v) { return wave_allreduce(v, OpSumLL()); }
 __device__ __forceinline__ double wave_max_d(double v) { return wave_allreduce(v, OpMaxD()); }
-// inclusive scan over the wave
+// inclusive scan over the wave: rocPRIM's DPP implementation (row_shr / row_bcast steps, VALU only) -- a __shfl_up
+// ladder is six ds_bpermute round trips through the LDS crossbar, ~700 cycles on a wave that has nothing else to do
+#ifdef BLU_EMU_BUILD
+struct OpSumIEmu { int lane; };
 __device__ __forceinline__ int wave_incl_scan_i(int v)
 {
+    int acc = 0;
     const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (l >= o) v += t;
+    for (int k = 0; k < 64; k++) { // (every lane takes part in all 64 exchanges: uniform control flow)
+        const int x = __shfl(v, k);
+        if (k <= l) acc += x;
     }
-    return v;
+    return acc;
 }
+#else
+__device__ __forceinline__ int wave_incl_scan_i(int v)
+{
+    using WS = rocprim::warp_scan<int, 64>;
+    typename WS::storage_type st; // empty for the DPP implementation
+    int out;
+    WS().inclusive_scan(v, out, st, rocprim::plus<int>());
+    return out;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // workgroup primitives (blockDim.x multiple of 64, <= 1024).  `sh` = 34 ints of LDS.

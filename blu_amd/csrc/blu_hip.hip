@@ -66,6 +66,7 @@ struct blu_hip {
     FinishOut *dO;
     FinishOut *oslot;
     int batch_block;   // workgroup size of the pivot kernel when this handle leads a batch
+    int batch_block_other, batch_block_stats; // workgroup sizes of k_prep / k_setup / k_finish and of k_stats in a batch
     int pivot_kernel;  // 0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = k_pivot_loop_wave, 2 = the multi-wave kernels
     int64_t out_lcap, out_ucap;
     // owned device copies of the caller's B (blu_hip_factorize with host arrays)
@@ -307,6 +308,11 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->oslot = h->dO;
     h->batch_block = 256;
     {   // diagnostic: which pivot kernel this handle launches (read once; blu_hip_dbg_set_pivot_kernel overrides)
+        const char *bo = getenv("BLU_BATCH_OTHER"), *bs = getenv("BLU_BATCH_STATS");
+        h->batch_block_other = bo ? atoi(bo) : 256;
+        h->batch_block_stats = bs ? atoi(bs) : 256;
+        if (h->batch_block_other < 64 || h->batch_block_other > 1024 || (h->batch_block_other & 63)) h->batch_block_other = 256;
+        if (h->batch_block_stats < 64 || h->batch_block_stats > 1024 || (h->batch_block_stats & 63)) h->batch_block_stats = 256;
         const char *pk = getenv("BLU_PIVOT_KERNEL");
         h->pivot_kernel = pk ? atoi(pk) : 0;
         if (h->pivot_kernel < 0 || h->pivot_kernel > 2) h->pivot_kernel = 0;

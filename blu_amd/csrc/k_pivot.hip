@@ -99,9 +99,13 @@ struct alignas(16) Sm {
     long long nfast[4];
     int sh[40];
     long long shl[20];
-    unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses
 #if BLU_CFG_WAVE
-    double swork[64]; // the dense work column of the one wave
+    unsigned long long wmax[1];
+#else
+    unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses
+#endif
+#if BLU_CFG_WAVE
+    double swork[WV_WCAP]; // the dense work column of the one wave (general paths: 64 entries) = the matrix of old values of k_pivot_wave.hip; all zero between pivots
 #else
     double swork[16 * 64]; // one dense work column per wave; LAST member: the batch kernel allocates 4 of the 16
 #endif

@@ -25,6 +25,24 @@
 // Lanes of a wave run in lockstep on the GPU; the CPU emulation build (emu/hip/hip_runtime.h) needs the places that
 // rely on it marked: WAVE_LOCKSTEP().
 
+// Diagnostic build (-DBLU_PROFILE, `make prof`): lane 0 adds the shader-clock ticks since the previous stamp to phase k
+// (tools/wave_phases.py prints the table).  The product build contains no stamps.
+#ifdef BLU_PROFILE
+#define WV_T(k)                                                                \
+    do {                                                                       \
+        if (lane_id() == 0) {                                                  \
+            const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
+            sm->prof[k] += t_ - g_pstamp[0];                                   \
+            sm->prof[24 + (k)] += 1;                                           \
+            g_pstamp[0] = t_;                                                  \
+        }                                                                      \
+    } while (0)
+#else
+#define WV_T(k) \
+    do {        \
+    } while (0)
+#endif
+
 __device__ __forceinline__ unsigned wv_hslot(int k) { return ((unsigned)k * 2654435761u) >> (32 - WV_HBITS); }
 __device__ __forceinline__ void wv_probe_overrun(int line)
 {
@@ -257,6 +275,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
     }
     if (kind == 2 && lane == 0) fa->pV[0] = pv1;
     wave_mem_sync();
+    WV_T(4);
     L.j = lane <= rnz1 ? fa->tJ[lane < rnz1 ? lane + 1 : 0] : -1; // lane rnz1: the pivot column
     L.cb = L.cl = L.cap = L.fl = L.bl = 0;
     if (lane <= rnz1) {
@@ -298,6 +317,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
         if ((long long)sm->cused + (both >> 32) > (long long)D.carena_cap || (long long)sm->rused + (both & 0xffffffffLL) > (long long)D.rarena_cap)
             kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
     }
+    WV_T(5);
     if (lane == 0) {
         fa->kind = kind;
         fa->where = wpos;
@@ -346,6 +366,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         wave_mem_sync();
         return true;
     }
+    WV_T(1);
     unsigned long long ne = __ballot(lane >= 1 && kk <= m && h != m + kk);
     if (!ne) return false; // (a long stretch of empty lists: the general search skips them 64 at a time)
     const int left = m - sm->rank - sm->rankdef; // every active column is in a count list; list 0 is empty
@@ -403,6 +424,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
                 j = fl;
             }
         }
+        WV_T(2);
         if (bad) return false; // reference: assert / D2; the general search raises it
         if (ncand < nsearched) return false; // more columns exist in lists beyond nz0+62
         if (total > WV_STG) return false;
@@ -443,6 +465,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         }
         const long long best = wave_min_ll(mcb);
         if (best == BIG) return false; // no eligible entry: cannot happen; the general search raises it
+        WV_T(3);
         const int fsel = (int)(best & 255LL);
         const int csel = (fsel >= off1) + (fsel >= off2) + (fsel >= off3);
         pc = fa->cJ[csel];
@@ -453,24 +476,37 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         nzr = __builtin_amdgcn_readlane(fsel < 64 ? rl0 : rl1, fsel & 63);
         prb = __builtin_amdgcn_readlane(fsel < 64 ? rb0 : rb1, fsel & 63);
     }
+    WV_T(1);
     return wv_layout(D, sm, L, pc, pr, nzc, pcb, nzr, prb, where, found_nz, nsearched, pv1);
 }
 
 // Segment bookkeeping of a flattened pass.  `hw` = head bits of this pass, `cbv` = (slot of the last line begun
-// before this pass); returns this lane's slot and tells whether it is the first / last lane of its line IN THIS PASS.
+// before this pass); gives this lane's slot, whether it is the last lane of its line IN THIS PASS, and what the
+// rank of an entry inside its line needs: the lanes below the line's first lane of this pass, and whether the line
+// continues from the previous pass (its count so far is then carried in a scalar, not read back from LDS).
 struct WvSeg {
     int c;
-    bool head, tail;
+    bool tail, first_seg;
+    unsigned long long below_h;
 };
 __device__ __forceinline__ WvSeg wv_segment(unsigned long long hw, int cbv, bool valid, bool lastflat)
 {
     const int lane = lane_id();
+    const unsigned long long le = (2ull << lane) - 1ull; // lanes at or below this one
     const int own = (int)((hw >> lane) & 1ull);
     WvSeg s;
     s.c = cbv + wave_prefix_count(hw) + own;
-    s.head = valid && (own || lane == 0);
+    const unsigned long long mine = (hw | 1ull) & le;
+    const int h = 63 - __clzll((long long)mine); // first lane of this lane's line in this pass
+    s.below_h = (1ull << h) - 1ull;
+    s.first_seg = (hw & le) == 0ull;
     s.tail = valid && (lane == 63 || lastflat || (((hw >> 1) >> lane) & 1ull));
     return s;
+}
+// rank of a kept entry among the kept entries of its line (kb = ballot of the kept ones)
+__device__ __forceinline__ int wv_rank(const WvSeg &sg, unsigned long long kb, int carry)
+{
+    return wave_prefix_count(kb) - __popcll(kb & sg.below_h) + (sg.first_seg ? carry : 0);
 }
 
 // One pass of a flattened phase, loads issued: which line each lane is in, the entry it holds.  The passes are
@@ -534,6 +570,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     }
     wave_mem_sync();
 
+    WV_T(6);
     // ================= column file update (pivot.rs:566-691) =================
     // per-lane constants of the paired pass: lane = (column cl_l of the pass, position p_l)
     const int Cper = 64 / cnz1;
@@ -564,7 +601,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         wave_mem_sync();
         // ---- pass A: every entry of the group's columns.  Entries whose row is in the pivot column leave the
         // column (their value goes to W); the others are compressed in place, keeping their order
-        int cbv = c0 - 1;
+        int cbv = c0 - 1, carry = 0;
         WvPass nx = wv_fetch<true>(D, fa, D.cidx, 0, Tg, f0, cbv);
         for (int k = 0; k * 64 < Tg; k++) {
             const WvPass P = nx;
@@ -578,12 +615,10 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             const bool hit = valid && p >= 0;
             const bool keep = valid && !hit;
             const bool ispr = keep && idx == pr;
-            if (hit) fa->W[(sg.c - c0) * cnz1 + p] = val;
+            if (hit) sm->swork[(sg.c - c0) * cnz1 + p] = val;
             const unsigned long long kb = __ballot(keep);
-            const int pre = wave_prefix_count(kb);
-            if (sg.head) fa->sSeg[sg.c] = pre - fa->sCnt[sg.c];
-            wave_mem_sync();
-            const int t = valid ? pre - fa->sSeg[sg.c] : 0;
+            const int t = valid ? wv_rank(sg, kb, carry) : 0;
+            carry = __builtin_amdgcn_readlane(t + (keep ? 1 : 0), 63); // (used only if the line at lane 63 goes on)
             if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
             if (ispr) {
                 fa->sX[sg.c] = val;
@@ -599,6 +634,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
                 atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
             }
         }
+        WV_T(7);
         wave_mem_sync();
         // ---- per column: kept count, room (file_reappend, file.rs:56-85), the deferred first entry, multiplier
         bool reloc = false;
@@ -639,6 +675,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             fa->sDst[lane] = dst + nk1;
         }
         wave_mem_sync();
+        WV_T(8);
         // ---- pass B: (column, position) pairs: work -= a * col (pivot.rs:623-625), append what stays above
         // droptol in pivot-column order (:630-664)
         int wbase = 0;
@@ -648,8 +685,8 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             double old = 0.0, a = 0.0;
             int dd = 0;
             if (act) {
-                old = fa->W[wbase + lane];
-                fa->W[wbase + lane] = 0.0;
+                old = sm->swork[wbase + lane];
+                sm->swork[wbase + lane] = 0.0;
                 a = fa->sX[c];
                 dd = fa->sDst[c];
             }
@@ -676,6 +713,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         wave_mem_sync();
     }
 
+    WV_T(9);
     // ---- per column: new metadata, U row (pivot.rs:666-672), new list key
     int newlen = -1;
     bool tiny = false;
@@ -701,6 +739,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     const unsigned long long tinyb = __ballot(tiny);
     const unsigned long long anycb = __ballot(anyc);
 
+    WV_T(10);
     // ================= row file update (pivot.rs:695-775) =================
     // columns of the pivot row -> slot (slot 0 = the pivot column): membership for the rows and for the list move
     wv_hclear(fa);
@@ -714,8 +753,9 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         atomicOr(&fa->zw[roff >> 6], 1ull << (roff & 63));
     }
     wave_mem_sync();
+    WV_T(11);
     {
-        int cbv = -1;
+        int cbv = -1, carry = 0;
         WvPass nx = wv_fetch<false>(D, fa, D.ridx, 0, Tr, 0, cbv);
         for (int k = 0; k * 64 < Tr; k++) {
             const WvPass P = nx;
@@ -725,15 +765,14 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             const int j = P.idx;
             const bool keep = valid && wv_hfind(fa, j) < 0; // overlap with the pivot row leaves, pivot column included
             const unsigned long long kb = __ballot(keep);
-            const int pre = wave_prefix_count(kb);
-            if (sg.head) fa->sSeg[sg.c] = pre - fa->sCnt[sg.c];
-            wave_mem_sync();
-            const int t = valid ? pre - fa->sSeg[sg.c] : 0;
+            const int t = valid ? wv_rank(sg, kb, carry) : 0;
+            carry = __builtin_amdgcn_readlane(t + (keep ? 1 : 0), 63);
             if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
             if (keep && t != P.e) D.ridx[P.bo.x + t] = j;
         }
     }
     wave_mem_sync();
+    WV_T(12);
     int rnk = 0, rdst = L.rb, rnewcap = L.rc;
     int rused = sm->rused;
     {
@@ -763,6 +802,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         if (lane < cnz1) fa->sDst[lane] = rdst + rnk;
     }
     wave_mem_sync();
+    WV_T(13);
     // ---- append the pattern of the pivot row, minus the cancelled positions (pivot.rs:752-758): (row, position) pairs
     int rnew = rnk + rnz1;
     {
@@ -796,6 +836,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         D.rcap[L.i] = rnewcap;
     }
 
+    WV_T(14);
     // ---- L column (pivot.rs:778-790)
     double lx = 0.0;
     if (lane < cnz1) lx = L.pv / pivot;
@@ -809,11 +850,13 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     }
     lused += __popcll(klb);
 
+    WV_T(15);
     // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
     // pivot-row order; the pivot column leaves
     int t_before;
     const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
 
+    WV_T(16);
     // ---- cleanup (pivot.rs:792-800)
     if (lane == 0) {
         const int rank = sm->rank;
@@ -835,6 +878,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     const int d3all = wave_sum_i(nd3);
     if (lane == 0 && d3all) sm->d3 += d3all;
     wave_mem_sync();
+    WV_T(17);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,6 +907,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
         atomicOr(&fa->zw[coff >> 6], 1ull << (coff & 63));
     }
     wave_mem_sync();
+    WV_T(18);
     int cbv = -1;
     for (int k = 0; k * 64 < Tc; k++) {
         const unsigned long long hw = fa->zw[k];
@@ -887,13 +932,16 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
                     fa->sM[sg.c] = (unsigned long long)__double_as_longlong(val);
                 }
             }
-            if (e == fa->sCnt[sg.c] - 1) {
+            // the last entry fills the hole -- needed only if it is not the pivot-row entry itself; (for a column of
+            // two it is then the entry recorded above: same bytes, same values)
+            if (e == fa->sCnt[sg.c] - 1 && idx != pr) {
                 fa->sK0i[sg.c] = idx;
                 fa->sK0v[sg.c] = val;
             }
         }
     }
     wave_mem_sync();
+    WV_T(19);
     int newlen = -1;
     double xrj = 0.0;
     bool tiny = false;
@@ -922,6 +970,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     }
     uused += __popcll(kub);
     const unsigned long long tinyb = __ballot(tiny);
+    WV_T(20);
     int t_before;
     const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
     // ---- hand-over to the next search.  A chain of column singletons (the triangular part of an LP basis: half of all
@@ -969,6 +1018,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
         sm->nfast[1]++;
     }
     wave_mem_sync();
+    WV_T(21);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1004,16 +1054,19 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         sm->flag_small = 0;
         fa->kind = 0;
         fa->nxValid = 0;
+#ifdef BLU_PROFILE
+        for (int k = 0; k < 48; k++) sm->prof[k] = 0;
+        g_pstamp[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
         sm->nfast[0] = sm->nfast[1] = sm->nfast[2] = sm->nfast[3] = 0;
         g_pivot_err = 0;
         g_pivot_err_line = 0;
     }
-    sm->swork[lane] = 0.0;
-    if (lane < 16) sm->wmax[lane] = 0ull;
+    for (int k = lane; k < WV_WCAP; k += 64) sm->swork[k] = 0.0;
+    if (lane == 0) sm->wmax[0] = 0ull;
     fa->zw[lane] = 0ull; // WV_ZW == 64
     fa->sMax[lane] = 0ull;
-    for (int k = lane; k < WV_WCAP; k += 64) fa->W[k] = 0.0;
     wave_mem_sync();
 
     WvLines L;
@@ -1029,6 +1082,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
             if (lane == 0) sm->exit_code = head_exit;
             break;
         }
+        WV_T(0);
         // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
         bool handled = false;
         if (need_search) {
@@ -1074,6 +1128,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
         else if (nz_col == 2) ok = pivot_doubleton_col(D, sm);
         else ok = pivot_general(D, sm, nz_col - 1 <= 64);
+        if (kind == 0) WV_T(23);
         if (!ok) break; // exit_code set, pivot stays pending
         // ---- remove columns whose maximum dropped below abstol (pivot.rs:98-106), record the pivot
         if (lane == 0) {
@@ -1094,6 +1149,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
             sm->rank = rank + 1;
         }
         wave_mem_sync();
+        WV_T(22);
     }
     wave_mem_sync();
     if (lane == 0) {
@@ -1114,6 +1170,9 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         S->d3_hits += sm->d3;
         for (int k = 0; k < 6; k++) S->npivot_kind[k] += sm->kinds[k];
         for (int k = 0; k < 4; k++) S->nfast[k] += sm->nfast[k];
+#ifdef BLU_PROFILE
+        for (int k = 0; k < 48; k++) S->prof[k] += sm->prof[k];
+#endif
         if (sm->exit_code == ST_ERROR && g_pivot_err_line) set_error(S, ST_ERROR, g_pivot_err_line);
         if (S->status == ST_RUNNING) S->status = sm->exit_code;
     }

@@ -34,18 +34,25 @@ struct Fast {
     unsigned long long hsh[WV_HASH]; // (key << 32) | value, ~0 = empty
     unsigned long long zw[WV_ZW];    // all zero between uses
     int2 sBO[WV_SLOTS];              // line of slot s: {begin, offset of its first entry in the flattened index space}
-    int sCnt[WV_SLOTS];              // entries kept so far (running, across the passes of a line)
-    int sSeg[WV_SLOTS];              // (ballot prefix at the line's first lane of this pass) - (kept before this pass)
-    int sW[WV_SLOTS];                // rank of the pivot-row entry among the kept entries
+    int sCnt[WV_SLOTS];              // entries kept (written by the last lane of the line in each pass)
     double sX[WV_SLOTS];             // pivot-row entry xrj, then the multiplier xrj / pivot
     unsigned long long sMax[WV_SLOTS]; // bit pattern of the line's new maximum, zero between uses
-    double sK0v[WV_SLOTS];           // first kept entry of the line (it goes where the pivot-row entry was, pivot.rs:261)
-    int sK0i[WV_SLOTS];
-    unsigned long long sM[WV_SLOTS]; // cancellation mask of the column (bit p = position p+1 of the pivot column, pivot.rs:645-664)
-    int sDst[WV_SLOTS];              // where the appended part of the line begins
-    int sNew[WV_SLOTS];              // entries appended
-    int tJ[WV_SLOTS + 1];            // pivot row, slot order
-    int pI[WV_SLOTS + 1];            // pivot column, slot order
-    double pV[WV_SLOTS + 1];
-    double W[WV_WCAP];               // all zero between pivots
+    // Three arrays live one after the other in the same bytes (slot by slot: a slot's earlier use is over before its
+    // later one begins -- the pivot column is read out when wv_small starts; a column's first kept entry is consumed
+    // by its group's epilogue before its pass B writes the mask / count):
+    union {
+        double pV[WV_SLOTS];             // pivot column values, slot order (slot 0 = the pivot)
+        double sK0v[WV_SLOTS];           // first kept entry of the line (it goes where the pivot-row entry was, pivot.rs:261)
+        unsigned long long sM[WV_SLOTS]; // cancellation mask of the column (bit p = position p+1 of the pivot column, pivot.rs:645-664)
+    };
+    union {
+        int pI[WV_SLOTS];                // pivot column row indices, slot order
+        int sK0i[WV_SLOTS];
+        int sNew[WV_SLOTS];              // entries appended
+    };
+    union {
+        int sW[WV_SLOTS];                // rank of the pivot-row entry among the kept entries (read by the epilogue ...)
+        int sDst[WV_SLOTS];              // ... which then writes where the appended part of the line begins)
+    };
+    int tJ[WV_SLOTS];                // pivot row, slot order
 };

@@ -1,0 +1,89 @@
+"""The pivot kernels stepped on the CPU: the emulation build of the library (blu_amd/csrc `make emu`: the same HIP
+sources compiled for the host, one fiber per GPU thread, emu/hip/hip_runtime.h) factorizes small bases with the
+one-wave-per-matrix kernel (k_pivot_loop_wave) and with the general pivot paths, and the results are compared with
+the oracle -- canonical factors, counters and the number of pivots per pivot routine, bit for bit.
+
+This is a DIAGNOSTIC build: the product path (libblu_hip.so) never loads it and has no CPU fallback.  It is what lets
+the wave-level kernel logic be checked in the CPU suite (and run under AddressSanitizer: `make emu_asan`).
+Each case runs in a child process: the library path is fixed when blu_amd is first imported."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "blu_amd", "csrc")
+EMU = os.path.join(ROOT, "blu_amd", "libblu_emu.so")
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import blu_amd
+from blu_amd import keys as K
+from oracle import orc
+assert b"gfx950" in blu_amd.lib().blu_hip_version()
+spec = %(spec)r
+no_fast = %(no_fast)r
+mats = [orc.gen_lp_basis(m, k, bw, tri, seed, offs) for (m, k, bw, tri, seed, offs) in spec]
+hs = [blu_amd.BLU(len(cp) - 1, len(ri)) for cp, ri, v in mats]
+for h in hs:
+    if no_fast:
+        h.dbg_set_no_fast(True)
+if len(hs) == 1:
+    cp, ri, v = mats[0]
+    st = [hs[0].factorize(cp[:-1], cp[1:], ri, v)]
+else:
+    st = blu_amd.factorize_batch(hs, mats)
+fast = 0
+for g, (cp, ri, v), s in zip(hs, mats, st):
+    m = len(cp) - 1
+    o = orc.OracleBLU(m, 64 * len(ri) + 1024)
+    o.set_fix_d3(True)
+    so = o.factorize(cp[:-1], cp[1:], ri, v)
+    assert s == so, (s, so)
+    fg, fo = g.get_factors(), o.get_factors()
+    for key in ("rowperm", "colperm", "l_colptr", "l_rowidx", "u_colptr", "u_rowidx", "l_value", "u_value"):
+        assert np.array_equal(fg[key], fo[key]), key
+    for cn in ("RANK", "L_NZ", "U_NZ", "NSEARCH_PIVOT", "FACTOR_FLOPS", "BUMP_NZ", "MATRIX_NZ"):
+        assert g.stat(getattr(K, "STAT_" + cn)) == o.stat(getattr(K, "STAT_" + cn)), cn
+    for kind in range(6):
+        assert g.stat(51 + kind) == o.stat(51 + kind), ("pivot kind", kind)
+    assert int(g.stat(50)) == o.d3_hits()
+    fast += int(g.stat(110)) + int(g.stat(111))
+print("FAST", fast)
+"""
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu"])
+    assert os.path.exists(EMU)
+    return EMU
+
+
+def run_child(emu_lib, spec, kernel, no_fast=False):
+    env = dict(os.environ, BLU_HIP_LIB=emu_lib, BLU_PIVOT_KERNEL=str(kernel))
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "spec": spec, "no_fast": no_fast}], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return int(out.stdout.split("FAST")[-1])
+
+
+@pytest.mark.parametrize("spec", [(300, 8, 8, 0.5, 1, 0.3), (500, 10, 9, 0.5, 7, 0.3), (400, 6, 20, 0.2, 3, 1.0), (250, 11, 30, 0.0, 5, 0.1)],
+                         ids=["banded", "c3-like", "wide", "no-triangle"])
+def test_wave_kernel_on_the_cpu(emu_lib, spec):
+    """k_pivot_loop_wave (flattened small / singleton-column paths, hand-over, general fallbacks), one basis"""
+    fast = run_child(emu_lib, [spec], kernel=1)
+    assert fast > spec[0] // 2  # most pivots took the flattened paths
+
+
+def test_wave_kernel_batch_on_the_cpu(emu_lib):
+    """the batch entry: three bases of different sizes, one wave each"""
+    fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6)], kernel=0)
+    assert fast > 300
+
+
+def test_general_paths_on_the_cpu(emu_lib):
+    """the general pivot paths alone (no flattened paths), as a workgroup of one wave"""
+    assert run_child(emu_lib, [(220, 8, 8, 0.5, 1, 0.3)], kernel=1, no_fast=True) == 0

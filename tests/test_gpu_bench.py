@@ -1,0 +1,27 @@
+"""bench.py on the GPU box under the launcher the driver uses (`python -m torch.distributed.run`), at world size 1:
+the child is started before anything in this process touches the GPU API on its behalf, initialises the `nccl`
+(= RCCL) process group, and runs the barrier / MAX / SUM reductions of blu_amd/shard.py around the timed region --
+the N > 1 code path, executed on real hardware with the one GPU a box has."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_under_torch_distributed_run_world_size_one():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C4", "--steps", "1", "--warmup", "0",
+           "--batch", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["workload"].startswith("C4") and rec["roofline"]["bound"] == "hbm"
+    assert "process group: nccl" in out.stderr + out.stdout

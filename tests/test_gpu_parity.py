@@ -358,6 +358,30 @@ def test_batch_of_independent_bases(blu, oracle):
     assert hs[0].factorize(mats[0][0][:-1], mats[0][0][1:], mats[0][1], mats[0][2]) == K.OK
 
 
+@pytest.mark.parametrize("spec", [(3000, 9, 10, 0.4, 17, 0.4), (2500, 10, 9, 0.5, 1, 0.3), (1800, 6, 30, 0.1, 9, 1.0)],
+                         ids=["mixed", "c3-like", "wide-band"])
+def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):
+    """A/B of the two pivot kernels on one basis -- k_pivot_loop_wave (one wave per matrix, flattened line updates: the
+    kernel of a batch) against k_pivot_loop (sixteen waves) -- and both against the oracle; the flattened paths must
+    have taken practically every small and singleton-column pivot."""
+    cp, ri, v = oracle.gen_lp_basis(*spec)
+    m = spec[0]
+    a, b = blu.BLU(m, len(ri)), blu.BLU(m, len(ri))
+    a.dbg_set_pivot_kernel(1)
+    b.dbg_set_pivot_kernel(2)
+    sa, sb = a.factorize(cp[:-1], cp[1:], ri, v), b.factorize(cp[:-1], cp[1:], ri, v)
+    o, so = util.oracle_factorize(oracle, cp, ri, v, allow_d3=True)
+    assert sa == sb == so == K.OK
+    fa, fb, fo = a.get_factors(), b.get_factors(), o.get_factors()
+    for k in util.INT_KEYS + util.VAL_KEYS:
+        assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], fo[k]), k
+    for c in util.COUNTERS:
+        assert a.stat(getattr(K, "STAT_" + c)) == b.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), c
+    for kind in range(6):
+        assert a.stat(51 + kind) == b.stat(51 + kind) == o.stat(51 + kind), kind
+    assert a.stat(110) + a.stat(111) >= 0.95 * (a.stat(52) + a.stat(54)) and b.stat(110) == 0
+
+
 def test_general_paths_only_matches_fast_paths(blu, oracle):
     """A/B of the two implementations of the pivot loop (LDS fast paths on / off)."""
     cp, ri, v = oracle.gen_lp_basis(3000, 9, 10, 0.4, 17, 0.4)
