@@ -101,6 +101,11 @@ __device__ __forceinline__ unsigned long long wv_bits_below(int n) { return n >=
 // What the search lays out for the pivot functions, one value per lane:
 //   lanes c < rnz1: column slot c+1 of the pivot row;  lane rnz1: the pivot column (its list links only)
 //   lanes p < cnz1: row slot p+1 of the pivot column (kind 1)
+// what the search hands to the pivot loop in (wave-uniform) registers: the same values it leaves in LDS for the
+// general paths, without the LDS round trip
+struct WvPick {
+    int pr, pc, nzc, nzr, kind, exit_code;
+};
 struct WvLines {
     int j, cb, cl, cap, fl, bl; // column: index, begin, length, capacity, count-list links
     int i, rb, rl, rc;          // row: index, begin, length, capacity
@@ -122,16 +127,14 @@ __device__ __forceinline__ int wv_lane_of(const Fast *fa, int e, bool want, int 
     const int s = wv_hfind(fa, e);
     return s < 0 ? -1 : (s == 0 ? n : s - 1);
 }
-// t_before: the tail of the lane's new list as it was before this batch (m + key = the list was empty)
+// t = the tail of the lane's new list, D.cblink[m + key], as loaded by the caller BEFORE the unlinks (a load the caller
+// can issue as soon as the keys are known and leave in flight over other work)
 __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int key, bool act, bool isgone, int fl, int bl, int n, int big,
-                                            int &t_before)
+                                            int t)
 {
     const int lane = lane_id();
     const int m = D.m;
     const bool unl = act || isgone;
-    int t = 0;
-    if (act) t = D.cblink[m + key]; // tail of the new list as it is BEFORE the unlinks
-    t_before = t;
     // lanes of equal key meet in an LDS word indexed by the key (all-zero between calls); large keys by ballots
     unsigned long long mygrp = 0ull;
     if (!__ballot(act && key >= WV_ZW)) {
@@ -199,7 +202,7 @@ __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int
 
 // Second half of the search: room in L and U, the kind of pivot, and -- for the two flattened kinds -- the pivot row
 // (and column) in slot order with the metadata of every line they touch.  pv1 = the pivot value of a column singleton.
-__device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, int pc, int pr, int nzc, int pcb, int nzr, int prb, int where,
+__device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, WvPick &P, int pc, int pr, int nzc, int pcb, int nzr, int prb, int where,
                                           int found_nz, int nsearched, double pv1)
 {
     const int lane = lane_id();
@@ -237,6 +240,12 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
         if (nzc == 1) kind = 2;
         else if (nzc >= 3 && nzc <= WV_SLOTS) kind = 1; // (64 lanes hold the pivot column: cnz1 <= 63)
     }
+    P.pr = pr;
+    P.pc = pc;
+    P.nzc = nzc;
+    P.nzr = nzr;
+    P.exit_code = exit_code;
+    P.kind = 0;
     if (kind == 0) {
         if (lane == 0) fa->kind = 0;
         wave_mem_sync();
@@ -259,6 +268,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
             sm->pr = -1;
             fa->kind = 0;
         }
+        P.pc = P.pr = -1;
         wave_mem_sync();
         return true;
     }
@@ -322,6 +332,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
         fa->kind = kind;
         fa->where = wpos;
     }
+    P.kind = kind;
     wave_mem_sync();
     return true;
 }
@@ -331,7 +342,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, in
 // path handles (nothing modified: the caller runs markowitz_wave).  On true: sm->pr / sm->pc are set (pr < 0: an
 // empty column was chosen; both < 0: error raised), fa->kind says which pivot function runs, L holds the lines.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
+__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, WvPick &P)
 {
     const int lane = lane_id();
     const int m = D.m;
@@ -351,7 +362,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         }
         const int pc = fa->nxPc, pr = fa->nxPr;
         const int left = m - sm->rank - sm->rankdef;
-        return wv_layout(D, sm, L, pc, pr, 1, fa->nxPcb, D.rlen[pr], D.rbeg[pr], 0, 1, left < K ? left : K, fa->nxVal);
+        return wv_layout(D, sm, L, P, pc, pr, 1, fa->nxPcb, D.rlen[pr], D.rbeg[pr], 0, 1, left < K ? left : K, fa->nxVal);
     }
     // heads of list 0 (lane 0) and of lists nz0 .. nz0+62 (lanes 1..63), one gather
     const int kk = lane == 0 ? 0 : nz0 + lane - 1;
@@ -363,6 +374,9 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
             sm->pr = -1;
             fa->kind = 0;
         }
+        P.pc = h0;
+        P.pr = -1;
+        P.nzc = P.nzr = P.kind = P.exit_code = 0;
         wave_mem_sync();
         return true;
     }
@@ -477,7 +491,7 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L)
         prb = __builtin_amdgcn_readlane(fsel < 64 ? rb0 : rb1, fsel & 63);
     }
     WV_T(1);
-    return wv_layout(D, sm, L, pc, pr, nzc, pcb, nzr, prb, where, found_nz, nsearched, pv1);
+    return wv_layout(D, sm, L, P, pc, pr, nzc, pcb, nzr, prb, where, found_nz, nsearched, pv1);
 }
 
 // Segment bookkeeping of a flattened pass.  `hw` = head bits of this pass, `cbv` = (slot of the last line begun
@@ -520,28 +534,29 @@ struct WvPass {
     int e, idx;
     double val;
 };
+// The loads are issued by EVERY lane on EVERY call (lanes past the end, and calls past the last pass, read entry 0 of
+// the arena): with a fixed number of loads in flight the compiler waits for "all but the newest two" when pass k is
+// worked on; loads under a branch would make it wait for everything, i.e. for the pass just fetched.
 template <bool VALUES>
 __device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idxarr, int k, int T, int f0, int &cbv)
 {
     const int lane = lane_id();
     WvPass P;
-    const unsigned long long hw = fa->zw[k];
+    const int kw = k < WV_ZW ? k : WV_ZW - 1; // (a call past the last pass: a word that is zero already)
+    const unsigned long long hw = fa->zw[kw];
     WAVE_LOCKSTEP();
-    if (lane == 0) fa->zw[k] = 0ull;
+    if (lane == 0) fa->zw[kw] = 0ull;
     const int f = k * 64 + lane;
     P.valid = f < T;
     P.sg = wv_segment(hw, cbv, P.valid, f == T - 1);
     cbv += __popcll(hw);
-    P.bo = make_int2(0, 0);
-    P.e = 0;
-    P.idx = -1;
+    P.bo = fa->sBO[P.valid ? P.sg.c : 0];
+    P.e = f + f0 - P.bo.y;
+    const int pos = P.valid ? P.bo.x + P.e : 0;
+    P.idx = idxarr[pos];
     P.val = 0.0;
-    if (P.valid) {
-        P.bo = fa->sBO[P.sg.c];
-        P.e = f + f0 - P.bo.y;
-        P.idx = idxarr[P.bo.x + P.e];
-        if (VALUES) P.val = D.cval[P.bo.x + P.e];
-    }
+    if (VALUES) P.val = D.cval[pos];
+    if (!P.valid) P.idx = -1;
     return P;
 }
 
@@ -602,10 +617,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         // ---- pass A: every entry of the group's columns.  Entries whose row is in the pivot column leave the
         // column (their value goes to W); the others are compressed in place, keeping their order
         int cbv = c0 - 1, carry = 0;
-        WvPass nx = wv_fetch<true>(D, fa, D.cidx, 0, Tg, f0, cbv);
-        for (int k = 0; k * 64 < Tg; k++) {
-            const WvPass P = nx;
-            if ((k + 1) * 64 < Tg) nx = wv_fetch<true>(D, fa, D.cidx, k + 1, Tg, f0, cbv);
+        const auto work_a = [&](const WvPass &P) {
             const WvSeg sg = P.sg;
             const bool valid = P.valid;
             const int2 bo = P.bo;
@@ -633,6 +645,16 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
                 }
                 atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
             }
+        };
+        // two passes per iteration, each with registers of its own: the pass being fetched never has to be copied
+        // into the registers of the pass being worked on (a copy waits for the loads: no overlap)
+        const int npass = (Tg + 63) >> 6;
+        WvPass PA = wv_fetch<true>(D, fa, D.cidx, 0, Tg, f0, cbv), PB = PA;
+        for (int k = 0; k < npass; k += 2) {
+            PB = wv_fetch<true>(D, fa, D.cidx, k + 1, Tg, f0, cbv);
+            work_a(PA);
+            PA = wv_fetch<true>(D, fa, D.cidx, k + 2, Tg, f0, cbv);
+            work_a(PB); // (past the last pass: every lane invalid, nothing happens)
         }
         WV_T(7);
         wave_mem_sync();
@@ -738,6 +760,10 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     uused += __popcll(kub);
     const unsigned long long tinyb = __ballot(tiny);
     const unsigned long long anycb = __ballot(anyc);
+    // tails of the columns' new count lists: the keys are final here, the lists are not touched until the list move
+    // below -- the load stays in flight over the whole row file update
+    int ltail = 0;
+    if (lane < rnz1) ltail = D.cblink[D.m + newlen];
 
     WV_T(10);
     // ================= row file update (pivot.rs:695-775) =================
@@ -756,10 +782,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     WV_T(11);
     {
         int cbv = -1, carry = 0;
-        WvPass nx = wv_fetch<false>(D, fa, D.ridx, 0, Tr, 0, cbv);
-        for (int k = 0; k * 64 < Tr; k++) {
-            const WvPass P = nx;
-            if ((k + 1) * 64 < Tr) nx = wv_fetch<false>(D, fa, D.ridx, k + 1, Tr, 0, cbv);
+        const auto work_r = [&](const WvPass &P) {
             const WvSeg sg = P.sg;
             const bool valid = P.valid;
             const int j = P.idx;
@@ -769,6 +792,14 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             carry = __builtin_amdgcn_readlane(t + (keep ? 1 : 0), 63);
             if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
             if (keep && t != P.e) D.ridx[P.bo.x + t] = j;
+        };
+        const int npass = (Tr + 63) >> 6;
+        WvPass PA = wv_fetch<false>(D, fa, D.ridx, 0, Tr, 0, cbv), PB = PA;
+        for (int k = 0; k < npass; k += 2) {
+            PB = wv_fetch<false>(D, fa, D.ridx, k + 1, Tr, 0, cbv);
+            work_r(PA);
+            PA = wv_fetch<false>(D, fa, D.ridx, k + 2, Tr, 0, cbv);
+            work_r(PB);
         }
     }
     wave_mem_sync();
@@ -853,8 +884,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     WV_T(15);
     // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
     // pivot-row order; the pivot column leaves
-    int t_before;
-    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, ltail);
 
     WV_T(16);
     // ---- cleanup (pivot.rs:792-800)
@@ -971,8 +1001,9 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     uused += __popcll(kub);
     const unsigned long long tinyb = __ballot(tiny);
     WV_T(20);
-    int t_before;
-    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, t_before);
+    int ltail = 0;
+    if (lane < rnz1) ltail = D.cblink[D.m + newlen];
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, ltail);
     // ---- hand-over to the next search.  A chain of column singletons (the triangular part of an LP basis: half of all
     // pivots) uncovers one singleton per pivot: if the count-1 list held nothing but this pivot column, its head is now the
     // first column this pivot left with one entry -- and that entry passed through the lanes above.  The next search
@@ -1070,13 +1101,17 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
     wave_mem_sync();
 
     WvLines L;
+    int rank = sm->rank, rankdef = sm->rankdef;
+    bool pending = sm->pc >= 0; // a pivot left pending by a NEED_* exit of the previous launch
     for (;;) {
         // ---- loop head: done / stop / error?
+        // (rank / rankdef / pending are wave-uniform registers kept beside their LDS copies, which the general paths read)
         int head_exit = 0;
         if (g_pivot_err) head_exit = ST_ERROR;
-        else if (sm->rank + sm->rankdef >= m) head_exit = ST_DONE;
-        else if (sm->stop_at >= 0 && sm->pc < 0 && sm->rank + sm->rankdef >= sm->stop_at) head_exit = ST_STOPPED;
-        const bool need_search = sm->pc < 0;
+        else if (rank + rankdef >= m) head_exit = ST_DONE;
+        else if (stop_at >= 0 && !pending && rank + rankdef >= stop_at) head_exit = ST_STOPPED;
+        const bool need_search = !pending;
+        pending = false;
         WAVE_LOCKSTEP();
         if (head_exit) {
             if (lane == 0) sm->exit_code = head_exit;
@@ -1085,8 +1120,9 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         WV_T(0);
         // ---- find pivot (skipped when a pivot is pending from a NEED_* exit, factorize_bump.rs:19-21)
         bool handled = false;
+        WvPick P;
         if (need_search) {
-            if (D.search_rows == 0 && !D.no_fast) handled = wv_search(D, sm, L);
+            if (D.search_rows == 0 && !D.no_fast) handled = wv_search(D, sm, L, P);
             if (!handled) {
                 if (D.search_rows == 0) markowitz_wave(D, sm);
                 else if (lane == 0) markowitz_serial(D, sm);
@@ -1097,11 +1133,16 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
             if (lane == 0) setup_pivot_general(D, sm);
             wave_mem_sync();
         }
-        const int pr = sm->pr, pc = sm->pc;
-        const int exit_code = sm->exit_code;
-        const int nz_col = sm->nzc, nz_row = sm->nzr;
-        const int kind = fa->kind;
-        WAVE_LOCKSTEP();
+        if (!handled) { // (the general search / a pending pivot: through LDS)
+            P.pr = sm->pr;
+            P.pc = sm->pc;
+            P.exit_code = sm->exit_code;
+            P.nzc = sm->nzc;
+            P.nzr = sm->nzr;
+            P.kind = fa->kind;
+            WAVE_LOCKSTEP();
+        }
+        const int pr = P.pr, pc = P.pc, exit_code = P.exit_code, nz_col = P.nzc, nz_row = P.nzr, kind = P.kind;
         if (pc < 0) { // no pivot found: the reference asserts (factorize_bump.rs:22)
             if (lane == 0) {
                 DEV_CHECK(S, false);
@@ -1113,9 +1154,10 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
             if (lane == 0) {
                 list_remove1(D.cflink, D.cblink, pc);
                 sm->pc = -1;
-                sm->rankdef++;
+                sm->rankdef = rankdef + 1;
                 sm->kinds[5]++;
             }
+            rankdef++;
             wave_mem_sync();
             continue;
         }
@@ -1132,7 +1174,6 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         if (!ok) break; // exit_code set, pivot stays pending
         // ---- remove columns whose maximum dropped below abstol (pivot.rs:98-106), record the pivot
         if (lane == 0) {
-            const int rank = sm->rank;
             if (sm->flag_small && nz_row > 1) {
                 for (int pos = D.ubeg[rank]; pos < D.ubeg[rank + 1]; pos++) {
                     const int j = D.uidx[pos];
@@ -1148,6 +1189,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
             sm->pr = -1;
             sm->rank = rank + 1;
         }
+        rank++;
         wave_mem_sync();
         WV_T(22);
     }
