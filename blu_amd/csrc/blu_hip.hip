@@ -67,8 +67,10 @@ struct blu_hip {
     FinishOut *oslot;
     int batch_block;   // workgroup size of the pivot kernel when this handle leads a batch
     int batch_block_other, batch_block_stats; // workgroup sizes of k_prep / k_setup / k_finish and of k_stats in a batch
+    int no_out_alias;  // diagnostic: 1 = canonical factors always in buffers of their own (see ensure_out)
     int pivot_kernel;  // 0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = k_pivot_loop_wave, 2 = the multi-wave kernels
     int64_t out_lcap, out_ucap;
+    bool out_in_arena; // the canonical L / U of the last factorize live inside the (then dead) column arena, not in buffers of their own
     // owned device copies of the caller's B (blu_hip_factorize with host arrays)
     unsigned long long *ob_begin, *ob_end, *ob_i;
     double *ob_x;
@@ -160,7 +162,7 @@ static void free_all(blu_hip *h)
     dfree(D.bc_idx); dfree(D.bc_val); dfree(D.bt_idx); dfree(D.bt_val);
     dfree(D.cidx); dfree(D.cval); dfree(D.ridx);
     dfree(D.lidx); dfree(D.uidx); dfree(D.lval); dfree(D.uval);
-    dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value);
+    if (!h->out_in_arena) { dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value); }
     dfree(h->ob_begin); dfree(h->ob_end); dfree(h->ob_i); dfree(h->ob_x);
     SparseWs &W = h->sw;
     dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.estack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
@@ -269,8 +271,10 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     // The reference starts with l_mem = u_mem = w_mem = b_nz and grows on demand (blu.rs:345-377).
     // HBM is plentiful: start roomy so that the pivot loop rarely has to leave the device.
     D.nzcap = (int)std::max<int64_t>(b_nz, 1);
-    D.lcap = (int)std::min<int64_t>(4 * b_nz + 4 * m + 64, kIntMax);
-    D.ucap = D.lcap;
+    // L and U: sized for the fill an LP basis typically has (C3: l_nz = 0.7 nnz, u_nz = 1.5 nnz), not for the worst case:
+    // a batch is limited by HBM capacity, and a factor that outgrows its storage costs one relaunch (ST_NEED_L / _U)
+    D.lcap = (int)std::min<int64_t>(2 * b_nz + 2 * m + 64, kIntMax);
+    D.ucap = (int)std::min<int64_t>(3 * b_nz + b_nz / 2 + 2 * m + 64, kIntMax);
     D.carena_cap = (int)std::min<int64_t>(6 * b_nz + 8 * m + 64, kIntMax);
     D.rarena_cap = D.carena_cap;
     bool ok = true;
@@ -313,6 +317,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         h->batch_block_stats = bs ? atoi(bs) : 256;
         if (h->batch_block_other < 64 || h->batch_block_other > 1024 || (h->batch_block_other & 63)) h->batch_block_other = 256;
         if (h->batch_block_stats < 64 || h->batch_block_stats > 1024 || (h->batch_block_stats & 63)) h->batch_block_stats = 256;
+        h->no_out_alias = getenv("BLU_NO_OUT_ALIAS") ? 1 : 0;
         const char *pk = getenv("BLU_PIVOT_KERNEL");
         h->pivot_kernel = pk ? atoi(pk) : 0;
         if (h->pivot_kernel < 0 || h->pivot_kernel > 2) h->pivot_kernel = 0;
@@ -555,18 +560,44 @@ static bool compact_file(blu_hip *h, int which, int need)
     return upload_desc(h);
 }
 
+// Room for the canonical factors (get_factors.rs:35-43: m + l_nz and m + u_nz entries of 16 bytes).  When the pivot loop
+// is over the active submatrix is gone and its column arena is dead storage until the next factorize -- which
+// invalidates these factors anyway -- so the canonical L goes into the arena's index array and the canonical U into its
+// value array whenever they fit (at C3: 13 of 15 MB and 25 of 30 MB; 38 MB less per handle, and HBM capacity is what
+// limits the number of bases of a batch).  Nothing but the pivot loop, k_compact and the debug dumps of a STOPPED
+// factorization reads the arenas.  Buffers of their own otherwise.
 // upload = false: the caller copies h->O to the handle's slot itself (a batch stages all of them in one copy)
 static bool ensure_out(blu_hip *h, int64_t ln, int64_t un, bool upload = true)
 {
-    if (ln > h->out_lcap) {
-        dfree(h->O.l_rowidx); dfree(h->O.l_value);
-        if (!dalloc(h, &h->O.l_rowidx, (size_t)ln) || !dalloc(h, &h->O.l_value, (size_t)ln)) return false;
-        h->out_lcap = ln;
-    }
-    if (un > h->out_ucap) {
-        dfree(h->O.u_rowidx); dfree(h->O.u_value);
-        if (!dalloc(h, &h->O.u_rowidx, (size_t)un) || !dalloc(h, &h->O.u_value, (size_t)un)) return false;
-        h->out_ucap = un;
+    const DevLU &D = h->D;
+    const bool fits = !h->no_out_alias && (size_t)ln * 16 <= (size_t)D.carena_cap * sizeof(int) && (size_t)un * 16 <= (size_t)D.carena_cap * sizeof(double);
+    if (fits) {
+        if (!h->out_in_arena) { // give the separate buffers back
+            dfree(h->O.l_rowidx); dfree(h->O.l_value); dfree(h->O.u_rowidx); dfree(h->O.u_value);
+            h->out_lcap = h->out_ucap = 0;
+        }
+        h->O.l_rowidx = (long long *)D.cidx;
+        h->O.l_value = (double *)((char *)D.cidx + (size_t)ln * 8);
+        h->O.u_rowidx = (long long *)D.cval;
+        h->O.u_value = (double *)((char *)D.cval + (size_t)un * 8);
+        h->out_in_arena = true;
+    } else {
+        if (h->out_in_arena) {
+            h->O.l_rowidx = h->O.u_rowidx = nullptr;
+            h->O.l_value = h->O.u_value = nullptr;
+            h->out_lcap = h->out_ucap = 0;
+            h->out_in_arena = false;
+        }
+        if (ln > h->out_lcap) {
+            dfree(h->O.l_rowidx); dfree(h->O.l_value);
+            if (!dalloc(h, &h->O.l_rowidx, (size_t)ln) || !dalloc(h, &h->O.l_value, (size_t)ln)) return false;
+            h->out_lcap = ln;
+        }
+        if (un > h->out_ucap) {
+            dfree(h->O.u_rowidx); dfree(h->O.u_value);
+            if (!dalloc(h, &h->O.u_rowidx, (size_t)un) || !dalloc(h, &h->O.u_value, (size_t)un)) return false;
+            h->out_ucap = un;
+        }
     }
     if (upload) HIP_TRY(h, hipMemcpy(h->oslot, &h->O, sizeof(FinishOut), hipMemcpyHostToDevice));
     return true;

