@@ -41,8 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--mods", type=int, default=1000, help="C5: column modifications per step")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1280, help="bases in flight for the secondary throughput measurement (0 = skip)")
-    ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the pivot kernel in batch mode")
+    ap.add_argument("--batch", type=int, default=1536, help="bases in flight for the secondary throughput measurement (0 = skip)")
+    ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the multi-wave pivot kernel in batch mode (BLU_PIVOT_KERNEL=2 only)")
     return ap.parse_args(argv)
 
 
@@ -82,9 +82,9 @@ def cpu_baseline(cp, ri, v, label, budget_s=12.0, max_reps=12):
 
 def batched_throughput(args, c, dev, local_rank, world, be):
     """SECONDARY measurement (never `value`): B independent bases of the same configuration in flight
-    on this GPU, one workgroup per basis (blu_hip_factorize_batch).  A single factorize is a chain of
-    dependent pivots and can not use more than one CU; this is the mode in which the chip fills up.
-    8 distinct matrices (seeds) are cycled over the B handles; inputs resident in HBM."""
+    on this GPU (blu_hip_factorize_batch), ONE WAVE per basis in the pivot kernel (k_pivot_loop_wave).  A
+    single factorize is a chain of dependent pivots and can not use more than one CU; this is the mode in
+    which the chip fills up.  8 distinct matrices (seeds) are cycled over the B handles; inputs resident in HBM."""
     import numpy as np
     import torch
     from blu_amd import keys as K, shard
@@ -111,19 +111,25 @@ def batched_throughput(args, c, dev, local_rank, world, be):
         if rep > 0 and (best is None or el < best[0]):
             F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs)
             lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
-            best = (el, hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP), int(hs[0].stat(K.STAT_DEV_RELAUNCHES)), F, lu)
+            best = (el, hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP), int(hs[0].stat(K.STAT_DEV_RELAUNCHES)), F, lu,
+                    [hs[0].stat(k) for k in (44, 45, 46, 47)],
+                    (hs[0].stat(110) + hs[0].stat(111)) / max(1.0, hs[0].stat(52) + hs[0].stat(54)))
     el = shard.max_over_ranks(best[0], dev)
-    t_piv, nl, F, lu = best[1], best[2], best[3], best[4]
+    t_piv, nl, F, lu, hs_phase, fast_share = best[1], best[2], best[3], best[4], best[5], best[6]
     gbs = (32.0 * F + 32.0 * lu) / t_piv / 1e9
     for h in hs:
         h.close()
     traffic = None
-    tinfo = _traffic_record("k_pivot_loop_batch")
+    wave = os.environ.get("BLU_PIVOT_KERNEL", "0") in ("0", "1")
+    kname = "k_pivot_loop_wave" if wave else "k_pivot_loop_batch"
+    tinfo = _traffic_record(kname)
     if tinfo and tinfo.get("bases") == B and tinfo.get("config") == args.config:
         traffic = tinfo["hbm_bytes_per_launch"] / max(t_piv / max(nl, 1), 1e-12) / 1e9
-    return {"bases_in_flight_per_gpu": B, "workgroup_threads": args.batch_block, "nnz_per_s": world * nnz / el,
+    return {"bases_in_flight_per_gpu": B, "workgroup_threads": 64 if wave else args.batch_block, "nnz_per_s": world * nnz / el,
             "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
-            "roofline": {"bound": "hbm", "kernel": "k_pivot_loop_batch (grid = %d workgroups)" % B, "achieved": gbs,
+            "phases_seconds": {"k_prep": hs_phase[0], "k_setup": hs_phase[1], "k_finish": hs_phase[2], "k_stats": hs_phase[3]},
+            "flattened_path_share": fast_share,
+            "roofline": {"bound": "hbm", "kernel": "%s (grid = %d workgroups)" % (kname, B), "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic},
             "note": "throughput mode, reported beside the headline; `value` above is ONE basis per GPU"}
 

@@ -428,9 +428,21 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case BLU_STAT_NGARBAGE: return (double)s.ngarbage;
     case BLU_STAT_FACTOR_FLOPS: return (double)s.factor_flops;
     case BLU_STAT_TIME_FACTORIZE: return h->t_total;
-    case BLU_STAT_TIME_SINGLETONS: return 0.0;
-    case BLU_STAT_TIME_SEARCH_PIVOT: return 0.0;
-    case BLU_STAT_TIME_ELIM_PIVOT: return h->t_pivot;
+    // lu.time_singletons / time_search_pivot / time_elim_pivot (lu.rs:560-572): device seconds of the last factorize.  The
+    // singleton phase is k_prep.  Search and elimination run inside ONE persistent kernel; its device time is split by
+    // the shader-clock phase counters of the diagnostic build (`make prof`: prof[0] = search + set-up of the multi-wave
+    // kernel) when they were collected, otherwise the whole kernel time is reported as elimination and the search as 0.
+    case BLU_STAT_TIME_SINGLETONS: return h->t_phase[0];
+    case BLU_STAT_TIME_SEARCH_PIVOT: {
+        double tot = 0.0;
+        for (int k = 0; k < 4; k++) tot += (double)s.prof[k];
+        return tot > 0.0 ? h->t_pivot * (double)s.prof[0] / tot : 0.0;
+    }
+    case BLU_STAT_TIME_ELIM_PIVOT: {
+        double tot = 0.0;
+        for (int k = 0; k < 4; k++) tot += (double)s.prof[k];
+        return tot > 0.0 ? h->t_pivot * (1.0 - (double)s.prof[0] / tot) : h->t_pivot;
+    }
     case BLU_STAT_UPDATE_COST_DENOM: // factorize.rs:160-166
         return 250.0 * (0.04 * (double)h->m + 0.07 * (double)s.matrix_nz + 0.20 * (double)s.bump_nz +
                         0.20 * (double)s.nsearch_pivot + 0.008 * (double)s.factor_flops);

@@ -1254,6 +1254,7 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
         for (int k = 0; k < 6; k++) sm->kinds[k] = 0;
 #ifdef BLU_PROFILE
         for (int k = 0; k < 48; k++) sm->prof[k] = 0;
+        for (int k = 0; k < 48; k++) g_pstamp[k] = 0;
 #endif
     }
     for (int k = tid; k < (int)blockDim.x; k += blockDim.x) sm->swork[k] = 0.0; // num_waves() x 64
@@ -1352,59 +1353,66 @@ __device__ __forceinline__ void pivot_loop_body(DevLU *Ds, int stop_at, Sm *sm, 
         if (!ok) break; // exit_code set, pivot stays pending
         PROF_STAMP(2);
 #ifdef BLU_PROFILE
+        // a stamp of a code path that did not run in this pivot is stale (or was never written): only differences of
+        // stamps taken in order inside THIS pivot are added
+#define PROF_ADD(k, a, b)                                                                                           \
+    do {                                                                                                            \
+        const long long d_ = g_pstamp[a] - g_pstamp[b];                                                             \
+        if (g_pstamp[b] >= g_pstamp[0] && d_ >= 0 && d_ < (1LL << 28)) sm->prof[k] += d_;                            \
+    } while (0)
         if (tid == 0) {
             const int kk = sm->fa.kind == 1 ? 1 : (sm->fa.kind == 2 ? 2 : 3);
-            sm->prof[0] += g_pstamp[1] - g_pstamp[0];  // search + set-up (incl. barrier)
-            sm->prof[kk] += g_pstamp[2] - g_pstamp[1]; // pivot: 1 fast small, 2 fast singleton col, 3 general paths
+            PROF_ADD(0, 1, 0);  // search + set-up (incl. barrier)
+            PROF_ADD(kk, 2, 1); // pivot: 1 fast small, 2 fast singleton col, 3 general paths
             sm->prof[3 + kk] += 1;                         // counts at 4,5,6
             if (kk == 1) {
-                sm->prof[7] += g_pstamp[3] - g_pstamp[1];   // fast small: line updates (rest = finalize)
+                PROF_ADD(7, 3, 1);   // fast small: line updates (rest = finalize)
                 // the finalize step, relative to the barrier after the line updates (stamp 3)
-                sm->prof[22] += g_pstamp[6] - g_pstamp[3];   // wave 0: U row written
-                sm->prof[23] += g_pstamp[24] - g_pstamp[3];  // wave 1: L column written
-                sm->prof[24] += g_pstamp[25] - g_pstamp[3];  // wave 2: list update entered
-                sm->prof[25] += g_pstamp[26] - g_pstamp[25]; //   links + tails loaded
-                sm->prof[26] += g_pstamp[27] - g_pstamp[26]; //   runs resolved (LDS pointer jumping)
-                sm->prof[27] += g_pstamp[28] - g_pstamp[27]; //   stores issued
-                sm->prof[30] += g_pstamp[30] - g_pstamp[27]; //     of which: runs unlinked
-                sm->prof[31] += g_pstamp[31] - g_pstamp[30]; //     tails resolved, same-key groups found
-                sm->prof[28] += g_pstamp[29] - g_pstamp[28]; //   stores drained
-                sm->prof[29] += g_pstamp[2] - g_pstamp[29];  // list wave done -> all waves past the last barrier
+                PROF_ADD(22, 6, 3);   // wave 0: U row written
+                PROF_ADD(23, 24, 3);  // wave 1: L column written
+                PROF_ADD(24, 25, 3);  // wave 2: list update entered
+                PROF_ADD(25, 26, 25); //   links + tails loaded
+                PROF_ADD(26, 27, 26); //   runs resolved (LDS pointer jumping)
+                PROF_ADD(27, 28, 27); //   stores issued
+                PROF_ADD(30, 30, 27); //     of which: runs unlinked
+                PROF_ADD(31, 31, 30); //     tails resolved, same-key groups found
+                PROF_ADD(28, 29, 28); //   stores drained
+                PROF_ADD(29, 2, 29);  // list wave done -> all waves past the last barrier
                 // the line updates, seen by wave 1 (its first three tasks; the first is a column)
                 sm->prof[32] += sm->nzr - 1;                 // tasks: columns
                 sm->prof[33] += sm->nzc - 1;                 //        rows
-                sm->prof[34] += g_pstamp[33] - g_pstamp[1];  // loads of the first three tasks issued
-                sm->prof[35] += g_pstamp[34] - g_pstamp[33]; // ... arrived
-                sm->prof[36] += g_pstamp[35] - g_pstamp[34]; // first task done
-                sm->prof[37] += g_pstamp[36] - g_pstamp[35]; // second task done
-                sm->prof[38] += g_pstamp[37] - g_pstamp[36]; // third task done
-                sm->prof[39] += g_pstamp[38] - g_pstamp[37]; // all of wave 1's tasks done, stores drained
-                sm->prof[40] += g_pstamp[3] - g_pstamp[38];  // ... until every wave is past the barrier
+                PROF_ADD(34, 33, 1);  // loads of the first three tasks issued
+                PROF_ADD(35, 34, 33); // ... arrived
+                PROF_ADD(36, 35, 34); // first task done
+                PROF_ADD(37, 36, 35); // second task done
+                PROF_ADD(38, 37, 36); // third task done
+                PROF_ADD(39, 38, 37); // all of wave 1's tasks done, stores drained
+                PROF_ADD(40, 3, 38);  // ... until every wave is past the barrier
                 if (g_pstamp[44] > g_pstamp[1]) { // speculative search of the next pivot on the unlink wave, relative to stamp 1
-                    sm->prof[41] += g_pstamp[41] - g_pstamp[1];  // columns of the pivot row unlinked
-                    sm->prof[42] += g_pstamp[42] - g_pstamp[41]; // walk
-                    sm->prof[43] += g_pstamp[43] - g_pstamp[42]; // staging
-                    sm->prof[44] += g_pstamp[44] - g_pstamp[43]; // reduction, result published
+                    PROF_ADD(41, 41, 1);  // columns of the pivot row unlinked
+                    PROF_ADD(42, 42, 41); // walk
+                    PROF_ADD(43, 43, 42); // staging
+                    PROF_ADD(44, 44, 43); // reduction, result published
                     sm->prof[45] += 1;
                 }
             }
             if (kk != 3) { // stages of the flattened search (stamps 8..14 set inside markowitz_fast)
-                sm->prof[8] += g_pstamp[8] - g_pstamp[0];   // head barrier -> search entered
-                sm->prof[9] += g_pstamp[9] - g_pstamp[8];   // walk: list heads + K link/meta loads
-                sm->prof[10] += g_pstamp[10] - g_pstamp[9]; // candidate entries + row metadata, costs
-                sm->prof[11] += g_pstamp[11] - g_pstamp[10]; // argmin
-                sm->prof[12] += g_pstamp[12] - g_pstamp[11]; // pivot column to LDS + pivot row load
-                sm->prof[13] += g_pstamp[13] - g_pstamp[12]; // column metadata + column hash
-                sm->prof[14] += g_pstamp[14] - g_pstamp[13]; // row hash + room sums
-                sm->prof[15] += g_pstamp[1] - g_pstamp[14]; // barrier after the search
+                PROF_ADD(8, 8, 0);   // head barrier -> search entered
+                PROF_ADD(9, 9, 8);   // walk: list heads + K link/meta loads
+                PROF_ADD(10, 10, 9); // candidate entries + row metadata, costs
+                PROF_ADD(11, 11, 10); // argmin
+                PROF_ADD(12, 12, 11); // pivot column to LDS + pivot row load
+                PROF_ADD(13, 13, 12); // column metadata + column hash
+                PROF_ADD(14, 14, 13); // row hash + room sums
+                PROF_ADD(15, 1, 14); // barrier after the search
                 // inside "candidate entries + row metadata": loads drained separately (PROF_WAIT)
                 if (g_pstamp[16] > g_pstamp[8]) { // (not a column-singleton search: those take mk_express)
-                    sm->prof[16] += g_pstamp[17] - g_pstamp[16]; // entries: address arithmetic + load + drain
-                    sm->prof[17] += g_pstamp[18] - g_pstamp[17]; // row metadata: load + drain
-                    sm->prof[18] += g_pstamp[10] - g_pstamp[18]; // LDS stores + costs
+                    PROF_ADD(16, 17, 16); // entries: address arithmetic + load + drain
+                    PROF_ADD(17, 18, 17); // row metadata: load + drain
+                    PROF_ADD(18, 10, 18); // LDS stores + costs
                     // inside the walk
-                    sm->prof[19] += g_pstamp[19] - g_pstamp[8];  // list heads loaded
-                    sm->prof[20] += g_pstamp[20] - g_pstamp[19]; // first candidate's link + metadata loaded
+                    PROF_ADD(19, 19, 8);  // list heads loaded
+                    PROF_ADD(20, 20, 19); // first candidate's link + metadata loaded
                     sm->prof[21] += 1;
                 }
             }

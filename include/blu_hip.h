@@ -75,6 +75,9 @@ enum blu_stat {
     BLU_STAT_NGARBAGE = 22,      /* layout dependent: not part of the parity contract */
     BLU_STAT_FACTOR_FLOPS = 23,  /* lu.rs:658 */
     BLU_STAT_TIME_FACTORIZE = 24,
+    /* 25-27: device seconds of the last factorize: singleton phase (k_prep); Markowitz search and elimination run inside
+     * one persistent kernel, whose time is split only by the diagnostic build with phase counters (otherwise
+     * TIME_SEARCH_PIVOT = 0 and TIME_ELIM_PIVOT = the whole pivot kernel) */
     BLU_STAT_TIME_SINGLETONS = 25,
     BLU_STAT_TIME_SEARCH_PIVOT = 26,
     BLU_STAT_TIME_ELIM_PIVOT = 27,

@@ -28,20 +28,27 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(R + "/gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            k = "k_pivot_loop_batch" if "k_pivot_loop_batch" in kn else ("k_pivot_loop" if "k_pivot_loop" in kn else None)
+            k = ("k_pivot_loop_wave" if "k_pivot_loop_wave" in kn else "k_pivot_loop_batch" if "k_pivot_loop_batch" in kn
+                 else ("k_pivot_loop" if "k_pivot_loop" in kn else None))
             if k and r["Counter_Name"] == c:
                 tot[k][c] += float(r["Counter_Value"]); n[k][c] += 1
 rec = {"kernel_source_sha16": bench.kernel_source_sha16(),
        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-include-regex k_pivot_loop -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --batch %d" % BATCH,
        "note": "FETCH_SIZE/WRITE_SIZE are reported in KB.  FETCH_SIZE is NOT doubled: the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide "
-               "(16 B/lane) coalesced streams; these kernels issue scattered 4- and 8-byte accesses, for which the counter is uncalibrated.  "
-               "Infinity-Cache hits are counted, not excluded.",
+               "(16 B/lane) coalesced streams; these kernels issue scattered 4- and 8-byte accesses -- see `calibration` (tools/pmc_calib.sh: what "
+               "the counters report for known-byte scattered gathers / scatters and for a 16-byte stream on this box).  Infinity-Cache hits are "
+               "counted, not excluded.",
        "kernels": {}}
 for k in tot:
     f = tot[k]["FETCH_SIZE"] / max(1, n[k]["FETCH_SIZE"]); w = tot[k]["WRITE_SIZE"] / max(1, n[k]["WRITE_SIZE"])
     rec["kernels"][k] = {"config": "C3", "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
                          "hbm_bytes_per_launch": 1024.0 * (f + w), "launches_seen": [n[k]["FETCH_SIZE"], n[k]["WRITE_SIZE"]]}
-    if k == "k_pivot_loop_batch": rec["kernels"][k]["bases"] = BATCH
+    if k in ("k_pivot_loop_batch", "k_pivot_loop_wave"): rec["kernels"][k]["bases"] = BATCH
+# calibration of the counters on known-byte kernels (tools/pmc_calib.sh), when it was collected on this box
+try:
+    rec["calibration"] = json.load(open(R + "/gpurun_out/pmc_calib.json"))
+except (OSError, ValueError):
+    rec["calibration"] = None
 os.makedirs(R + "/gpurun_out", exist_ok=True)
 json.dump(rec, open(R + "/gpurun_out/pivot_loop_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
