@@ -200,6 +200,100 @@ __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int
     return minall;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The list walk of a search (markowitz.rs:73-123: the first maxsearch columns in count-list order) as a resumable
+// sequence of steps, one memory round trip each: the list heads, then link + metadata of one candidate column at a
+// time.  A search runs the steps back to back.  A pivot_small STARTS the walk of the NEXT search as soon as its own
+// list move is done (lists and column metadata are final then, unless a column has to be removed) and advances it
+// one step at each stage of the rest of its work -- row epilogue, row append, L column, clean-up, pivot record --
+// so that the next search finds its candidates waiting: the walk is the longest dependent chain of a search.
+// ------------------------------------------------------------------------------------------------
+struct WvWalk {
+    int st;     // 0 idle, 1 list heads in flight, 2 a candidate in flight, 3 done: candidates in fa->c*, 4 not handled here (the
+                // general search decides), 5 an empty column heads list 0, 6 a column singleton heads list 1
+    int nz0, h; // h: one list head per lane (lane 0: list 0; lane l: list nz0 + l - 1)
+    unsigned long long ne;
+    int j, znz, ncand, total, found_nz, guard;
+    int fl, cb, cl; // in flight: link, begin, length, maximum of column j
+    double cmx;
+};
+__device__ __forceinline__ void ew_issue(const DevGP &D, WvWalk &E)
+{
+    E.fl = D.cflink[E.j];
+    E.cb = D.cbeg[E.j];
+    E.cl = D.clen[E.j];
+    E.cmx = D.colmax[E.j];
+}
+__device__ __forceinline__ void ew_begin(const DevGP &D, WvWalk &E, int nz0)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    E.nz0 = nz0;
+    const int kk = lane == 0 ? 0 : nz0 + lane - 1;
+    E.h = kk <= m ? D.cflink[m + kk] : m + kk;
+    E.ne = 0ull;
+    E.j = 0;
+    E.znz = E.ncand = E.total = E.guard = 0;
+    E.found_nz = -1;
+    E.fl = E.cb = E.cl = 0;
+    E.cmx = 0.0;
+    E.st = nz0 >= 1 ? 1 : 4;
+}
+// the next list with a member, or the end of the walk
+__device__ __forceinline__ void ew_next_list(const DevGP &D, WvWalk &E)
+{
+    if (E.ne) {
+        const int b = __ffsll((long long)E.ne) - 1;
+        E.ne &= E.ne - 1;
+        E.j = __builtin_amdgcn_readlane(E.h, b);
+        E.znz = E.nz0 + b - 1;
+        E.guard = 0;
+        ew_issue(D, E);
+        E.st = 2;
+    } else {
+        E.st = 3;
+    }
+}
+__device__ __forceinline__ void ew_step(const DevGP &D, Sm *sm, WvWalk &E, int K)
+{
+    const int lane = lane_id();
+    const int m = D.m;
+    Fast *fa = &sm->fa;
+    if (E.st == 1) {
+        const int kk = lane == 0 ? 0 : E.nz0 + lane - 1;
+        const int h0 = __builtin_amdgcn_readlane(E.h, 0);
+        E.ne = __ballot(lane >= 1 && kk <= m && E.h != m + kk);
+        if (h0 != m) E.st = 5;                         // empty column: chosen immediately (markowitz.rs:73-78)
+        else if (!E.ne) E.st = 4;                      // (a long stretch of empty lists: the general search skips them 64 at a time)
+        else if (E.nz0 == 1 && (E.ne & 2ull)) E.st = 6; // a column singleton
+        else ew_next_list(D, E);
+    } else if (E.st == 2) {
+        if (E.cl != E.znz || E.cmx == 0.0 || !(E.cmx >= D.abstol) || ++E.guard > m + 2) {
+            E.st = 4; // reference: assert / D2; the general search raises it
+            return;
+        }
+        if (lane == 0) {
+            fa->cJ[E.ncand] = E.j;
+            fa->cNz[E.ncand] = E.znz;
+            fa->cB[E.ncand] = E.cb;
+            fa->cL[E.ncand] = E.cl;
+            fa->cMx[E.ncand] = E.cmx;
+            fa->cOff[E.ncand] = E.total;
+        }
+        if (E.found_nz < 0) E.found_nz = E.znz;
+        E.total += E.cl;
+        E.ncand++;
+        if (E.ncand >= K) {
+            E.st = 3;
+        } else if (E.fl < m) {
+            E.j = E.fl;
+            ew_issue(D, E);
+        } else {
+            ew_next_list(D, E);
+        }
+    }
+}
+
 // Second half of the search: room in L and U, the kind of pivot, and -- for the two flattened kinds -- the pivot row
 // (and column) in slot order with the metadata of every line they touch.  pv1 = the pivot value of a column singleton.
 __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, WvPick &P, int pc, int pr, int nzc, int pcb, int nzr, int prb, int where,
@@ -342,20 +436,22 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, Wv
 // path handles (nothing modified: the caller runs markowitz_wave).  On true: sm->pr / sm->pc are set (pr < 0: an
 // empty column was chosen; both < 0: error raised), fa->kind says which pivot function runs, L holds the lines.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, WvPick &P)
+__device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, WvPick &P, WvWalk &E)
 {
     const int lane = lane_id();
     const int m = D.m;
     Scalars *S = D.s;
     Fast *fa = &sm->fa;
     const int K = D.maxsearch;
-    if (K < 1 || K > KCMAX || m >= (1 << 27)) return false; // (cost * 256 + position must fit 64 bits)
-    const int nz0 = sm->min_colnz;
-    if (nz0 < 1) return false;
+    if (K < 1 || K > KCMAX || m >= (1 << 27)) { // (cost * 256 + position must fit 64 bits)
+        E.st = 0;
+        return false;
+    }
     const bool handed = fa->nxValid != 0;
     WAVE_LOCKSTEP();
     if (handed) {
         // ---- the previous pivot (a column singleton) left the next one: see wv_scol
+        E.st = 0;
         if (lane == 0) {
             fa->nxValid = 0;
             sm->nfast[2]++;
@@ -364,11 +460,15 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, Wv
         const int left = m - sm->rank - sm->rankdef;
         return wv_layout(D, sm, L, P, pc, pr, 1, fa->nxPcb, D.rlen[pr], D.rbeg[pr], 0, 1, left < K ? left : K, fa->nxVal);
     }
-    // heads of list 0 (lane 0) and of lists nz0 .. nz0+62 (lanes 1..63), one gather
-    const int kk = lane == 0 ? 0 : nz0 + lane - 1;
-    const int h = kk <= m ? D.cflink[m + kk] : m + kk;
-    const int h0 = __builtin_amdgcn_readlane(h, 0);
-    if (h0 != m) { // empty column: chosen immediately (markowitz.rs:73-78)
+    // ---- the list walk: started by the previous pivot (see WvWalk), or from scratch
+    if (E.st == 0) ew_begin(D, E, sm->min_colnz);
+    else if (lane == 0) sm->nfast[3]++;
+    while (E.st == 1 || E.st == 2) ew_step(D, sm, E, K);
+    const int wst = E.st;
+    E.st = 0;
+    if (wst == 4) return false;
+    if (wst == 5) {
+        const int h0 = __builtin_amdgcn_readlane(E.h, 0);
         if (lane == 0) {
             sm->pc = h0;
             sm->pr = -1;
@@ -380,18 +480,16 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, Wv
         wave_mem_sync();
         return true;
     }
-    WV_T(1);
-    unsigned long long ne = __ballot(lane >= 1 && kk <= m && h != m + kk);
-    if (!ne) return false; // (a long stretch of empty lists: the general search skips them 64 at a time)
+    WV_T(2);
     const int left = m - sm->rank - sm->rankdef; // every active column is in a count list; list 0 is empty
     const int nsearched = left < K ? left : K;
 
     int pc, pr, nzc, pcb, nzr, prb, where, found_nz;
     double pv1 = 0.0;
-    if (nz0 == 1 && (ne & 2ull)) {
+    if (wst == 6) {
         // ---- column singleton: its one entry costs 0 and no later candidate can be strictly cheaper
         // (markowitz.rs:105); the reference still looks at maxsearch columns, which only shows in nsearch_pivot
-        pc = __builtin_amdgcn_readlane(h, 1);
+        pc = __builtin_amdgcn_readlane(E.h, 1);
         pcb = D.cbeg[pc];
         const int cl = D.clen[pc];
         const double cmx = D.colmax[pc];
@@ -407,39 +505,8 @@ __device__ __forceinline__ bool wv_search(const DevGP &D, Sm *sm, WvLines &L, Wv
         where = 0;
         found_nz = 1;
     } else {
-        // ---- walk the lists to the first K columns (dependent loads: link + metadata of one column at a time)
-        int ncand = 0, total = 0;
-        bool bad = false;
-        found_nz = -1;
-        while (ne && ncand < K && !bad) {
-            const int b = __ffsll((long long)ne) - 1;
-            ne &= ne - 1;
-            int j = __builtin_amdgcn_readlane(h, b);
-            const int znz = nz0 + b - 1;
-            int guard = 0;
-            while (j < m && ncand < K) {
-                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
-                const double cmx = D.colmax[j];
-                if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
-                    bad = true;
-                    break;
-                }
-                if (lane == 0) {
-                    fa->cJ[ncand] = j;
-                    fa->cNz[ncand] = znz;
-                    fa->cB[ncand] = cb;
-                    fa->cL[ncand] = cl;
-                    fa->cMx[ncand] = cmx;
-                    fa->cOff[ncand] = total;
-                }
-                if (found_nz < 0) found_nz = znz;
-                total += cl;
-                ncand++;
-                j = fl;
-            }
-        }
-        WV_T(2);
-        if (bad) return false; // reference: assert / D2; the general search raises it
+        const int ncand = E.ncand, total = E.total;
+        found_nz = E.found_nz;
         if (ncand < nsearched) return false; // more columns exist in lists beyond nz0+62
         if (total > WV_STG) return false;
         if (lane == 0) fa->cOff[ncand] = total;
@@ -563,7 +630,7 @@ __device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idx
 // ------------------------------------------------------------------------------------------------
 // pivot_small (pivot.rs:460-833), pivot row of <= 64 entries
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &L, int pr, int pc, int nz_col, int nz_row)
+__device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &L, WvWalk &E, int pr, int pc, int nz_col, int nz_row)
 {
     const int lane = lane_id();
     Scalars *S = D.s;
@@ -804,6 +871,19 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     }
     wave_mem_sync();
     WV_T(12);
+    // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
+    // pivot-row order; the pivot column leaves.  (Here, not at the end: the tails arrived during the rows pass, and
+    // from here on the lists are final -- the walk of the next search can start.)
+    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, ltail);
+    {
+        const int K = D.maxsearch;
+        E.st = 0;
+        if (!tinyb && D.search_rows == 0 && !D.no_fast && K >= 1 && K <= KCMAX) { // (a column to be removed would change the lists again)
+            const int cur = sm->min_colnz;
+            ew_begin(D, E, mn < cur ? mn : cur);
+        }
+    }
+    WV_T(17);
     int rnk = 0, rdst = L.rb, rnewcap = L.rc;
     int rused = sm->rused;
     {
@@ -833,6 +913,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         if (lane < cnz1) fa->sDst[lane] = rdst + rnk;
     }
     wave_mem_sync();
+    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
     WV_T(13);
     // ---- append the pattern of the pivot row, minus the cancelled positions (pivot.rs:752-758): (row, position) pairs
     int rnew = rnk + rnz1;
@@ -867,6 +948,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         D.rcap[L.i] = rnewcap;
     }
 
+    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
     WV_T(14);
     // ---- L column (pivot.rs:778-790)
     double lx = 0.0;
@@ -880,14 +962,15 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         D.lval[d] = lx;
     }
     lused += __popcll(klb);
+#ifdef WV_DEBUG_HAND
+    if (lane == 0) printf("L column: rank %d cnz1 %d klb %llx sm->lused %d lused(after) %d lidx %p\n", sm->rank, cnz1, klb, sm->lused, lused, (void *)(int *)D.lidx);
+#endif
 
     WV_T(15);
-    // ---- column count lists (pivot.rs:682-683, :797): every column of the pivot row to the list of its new count, in
-    // pivot-row order; the pivot column leaves
-    const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, ltail);
-
+    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
     WV_T(16);
     // ---- cleanup (pivot.rs:792-800)
+    WAVE_LOCKSTEP(); // (every lane has read sm->lused above before lane 0 replaces it)
     if (lane == 0) {
         const int rank = sm->rank;
         D.ubeg[rank + 1] = uused;
@@ -908,7 +991,8 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     const int d3all = wave_sum_i(nd3);
     if (lane == 0 && d3all) sm->d3 += d3all;
     wave_mem_sync();
-    WV_T(17);
+    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+    WV_T(16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1101,6 +1185,8 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
     wave_mem_sync();
 
     WvLines L;
+    WvWalk E;
+    E.st = 0;
     int rank = sm->rank, rankdef = sm->rankdef;
     bool pending = sm->pc >= 0; // a pivot left pending by a NEED_* exit of the previous launch
     for (;;) {
@@ -1122,7 +1208,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         bool handled = false;
         WvPick P;
         if (need_search) {
-            if (D.search_rows == 0 && !D.no_fast) handled = wv_search(D, sm, L, P);
+            if (D.search_rows == 0 && !D.no_fast) handled = wv_search(D, sm, L, P, E);
             if (!handled) {
                 if (D.search_rows == 0) markowitz_wave(D, sm);
                 else if (lane == 0) markowitz_serial(D, sm);
@@ -1164,7 +1250,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         // ---- pivot(): the room check of pivot.rs:70-81 was made by the search; dispatch (:84-94)
         if (exit_code) break;
         bool ok = true;
-        if (kind == 1) wv_small(D, sm, L, pr, pc, nz_col, nz_row);
+        if (kind == 1) wv_small(D, sm, L, E, pr, pc, nz_col, nz_row);
         else if (kind == 2) wv_scol(D, sm, L, pr, pc, nz_row);
         else if (nz_row == 1) ok = pivot_singleton_row(D, sm);
         else if (nz_col == 1) ok = pivot_singleton_col(D, sm);
@@ -1191,6 +1277,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         }
         rank++;
         wave_mem_sync();
+        if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
         WV_T(22);
     }
     wave_mem_sync();

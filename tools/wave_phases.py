@@ -24,13 +24,13 @@ for rep in range(2):
 names = ["loop head", "search: heads / express / hand-over", "search: walk", "search: stage + reduce", "layout: pivot row+col -> slots",
          "layout: line metadata, sums", "small: row hash, offsets", "small: pass A", "small: column epilogue (+re-append)", "small: pass B",
          "small: column finalize, U", "small: column hash, offsets", "small: rows pass", "small: row epilogue", "small: row append",
-         "small: L column", "small: list move", "small: cleanup", "scol: hash, offsets", "scol: pass", "scol: finalize, U",
+         "small: L column", "small: cleanup", "small: list move, walk of the next search begun", "scol: hash, offsets", "scol: pass", "scol: finalize, U",
          "scol: list move, hand-over, cleanup", "record pivot", "general paths"]
 h = hs[0]
 tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
 tot = sum(h.stat(60 + k) for k in range(24))
 npiv = h.stat(52) + h.stat(54)
-print("B=%d %s: pivot kernel %.3f s; basis 0: %.0f ticks in %d pivots (small %d, scol %d; handed %d)" % (B, cfg, tp, tot, npiv, h.stat(54), h.stat(52), h.stat(116)))
+print("B=%d %s: pivot kernel %.3f s; basis 0: %.0f ticks in %d pivots (small %d, scol %d; searches handed over %d, with the walk begun early %d)" % (B, cfg, tp, tot, npiv, h.stat(54), h.stat(52), h.stat(116), h.stat(117)))
 for k, nm in enumerate(names):
     t, n = h.stat(60 + k), h.stat(84 + k)
     if n:
