@@ -208,6 +208,15 @@ __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int
 // one step at each stage of the rest of its work -- row epilogue, row append, L column, clean-up, pivot record --
 // so that the next search finds its candidates waiting: the walk is the longest dependent chain of a search.
 // ------------------------------------------------------------------------------------------------
+// MEASURED (round 3, MI355X): with the early start the walk disappears from the search (7 240 -> 1 070 ticks per search)
+// but every stage that advances it gets ~2 000 ticks slower, and the pivot kernel as a whole 7 % slower (C2: 0.146 ->
+// 0.156 s at 1024 bases, C3: 2.10 -> 2.23 s at 1536): a step has to wait for its loads with s_waitcnt vmcnt, and on
+// gfx950 loads and stores share that in-order counter -- the wait also drains the scattered stores the stage before
+// has just issued, which nothing waits for otherwise.  So the early start is OFF (WV_EARLY_WALK 0); a search runs the
+// steps back to back.
+#ifndef WV_EARLY_WALK
+#define WV_EARLY_WALK 0
+#endif
 struct WvWalk {
     int st;     // 0 idle, 1 list heads in flight, 2 a candidate in flight, 3 done: candidates in fa->c*, 4 not handled here (the
                 // general search decides), 5 an empty column heads list 0, 6 a column singleton heads list 1
@@ -878,7 +887,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     {
         const int K = D.maxsearch;
         E.st = 0;
-        if (!tinyb && D.search_rows == 0 && !D.no_fast && K >= 1 && K <= KCMAX) { // (a column to be removed would change the lists again)
+        if (WV_EARLY_WALK && !tinyb && D.search_rows == 0 && !D.no_fast && K >= 1 && K <= KCMAX) { // (a column to be removed would change the lists again)
             const int cur = sm->min_colnz;
             ew_begin(D, E, mn < cur ? mn : cur);
         }
@@ -913,7 +922,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         if (lane < cnz1) fa->sDst[lane] = rdst + rnk;
     }
     wave_mem_sync();
-    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+    if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
     WV_T(13);
     // ---- append the pattern of the pivot row, minus the cancelled positions (pivot.rs:752-758): (row, position) pairs
     int rnew = rnk + rnz1;
@@ -948,7 +957,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
         D.rcap[L.i] = rnewcap;
     }
 
-    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+    if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
     WV_T(14);
     // ---- L column (pivot.rs:778-790)
     double lx = 0.0;
@@ -967,7 +976,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
 #endif
 
     WV_T(15);
-    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+    if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
     WV_T(16);
     // ---- cleanup (pivot.rs:792-800)
     WAVE_LOCKSTEP(); // (every lane has read sm->lused above before lane 0 replaces it)
@@ -991,7 +1000,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     const int d3all = wave_sum_i(nd3);
     if (lane == 0 && d3all) sm->d3 += d3all;
     wave_mem_sync();
-    if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+    if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
     WV_T(16);
 }
 
@@ -1021,6 +1030,9 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
         atomicOr(&fa->zw[coff >> 6], 1ull << (coff & 63));
     }
     wave_mem_sync();
+    // tails of the columns' new count lists (every column loses exactly one entry): in flight over the pass below
+    int ltail = 0;
+    if (lane < rnz1) ltail = D.cblink[D.m + L.cl - 1];
     WV_T(18);
     int cbv = -1;
     for (int k = 0; k * 64 < Tc; k++) {
@@ -1085,8 +1097,6 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     uused += __popcll(kub);
     const unsigned long long tinyb = __ballot(tiny);
     WV_T(20);
-    int ltail = 0;
-    if (lane < rnz1) ltail = D.cblink[D.m + newlen];
     const int mn = wv_list_move(D, fa, L.j, newlen, lane < rnz1, lane == rnz1, L.fl, L.bl, rnz1, D.m + 2, ltail);
     // ---- hand-over to the next search.  A chain of column singletons (the triangular part of an LP basis: half of all
     // pivots) uncovers one singleton per pivot: if the count-1 list held nothing but this pivot column, its head is now the
@@ -1277,7 +1287,7 @@ __device__ __forceinline__ void pivot_loop_wave(DevLU *Ds, int stop_at, Sm *sm)
         }
         rank++;
         wave_mem_sync();
-        if (E.st == 1 || E.st == 2) ew_step(D, sm, E, D.maxsearch);
+        if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
         WV_T(22);
     }
     wave_mem_sync();
