@@ -41,6 +41,7 @@ def parse_args(argv=None):
     ap.add_argument("--mods", type=int, default=1000, help="C5: column modifications per step")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the pivot kernel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch-sizes", action="store_true", help="skip the batched measurement on C4- and C2-size bases")
     ap.add_argument("--batch", type=int, default=1536, help="bases in flight for the secondary throughput measurement (0 = skip)")
     ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the multi-wave pivot kernel in batch mode (BLU_PIVOT_KERNEL=2 only)")
     return ap.parse_args(argv)
@@ -80,7 +81,7 @@ def cpu_baseline(cp, ri, v, label, budget_s=12.0, max_reps=12):
             "seconds_per_factorize": med}
 
 
-def batched_throughput(args, c, dev, local_rank, world, be):
+def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=None):
     """SECONDARY measurement (never `value`): B independent bases of the same configuration in flight
     on this GPU (blu_hip_factorize_batch), ONE WAVE per basis in the pivot kernel (k_pivot_loop_wave).  A
     single factorize is a chain of dependent pivots and can not use more than one CU; this is the mode in
@@ -88,7 +89,8 @@ def batched_throughput(args, c, dev, local_rank, world, be):
     import numpy as np
     import torch
     from blu_amd import keys as K, shard
-    B = args.batch
+    B = args.batch if B is None else B
+    cfg_name = args.config if cfg_name is None else cfg_name
     nd = min(B, 8)
     mats = []
     for s in range(nd):
@@ -123,9 +125,9 @@ def batched_throughput(args, c, dev, local_rank, world, be):
     wave = os.environ.get("BLU_PIVOT_KERNEL", "0") in ("0", "1")
     kname = "k_pivot_loop_wave" if wave else "k_pivot_loop_batch"
     tinfo = _traffic_record(kname)
-    if tinfo and tinfo.get("bases") == B and tinfo.get("config") == args.config:
+    if tinfo and tinfo.get("bases") == B and tinfo.get("config") == cfg_name:
         traffic = tinfo["hbm_bytes_per_launch"] / max(t_piv / max(nl, 1), 1e-12) / 1e9
-    return {"bases_in_flight_per_gpu": B, "workgroup_threads": 64 if wave else args.batch_block, "nnz_per_s": world * nnz / el,
+    return {"config": "%s-size bases (m = %d)" % (cfg_name, c["m"]), "bases_in_flight_per_gpu": B, "workgroup_threads": 64 if wave else args.batch_block, "nnz_per_s": world * nnz / el,
             "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
             "phases_seconds": {"k_prep": hs_phase[0], "k_setup": hs_phase[1], "k_finish": hs_phase[2], "k_stats": hs_phase[3]},
             "flattened_path_share": fast_share,
@@ -345,6 +347,12 @@ def rank_main(args, backend=None, device=None):
     }
     if args.batch > 0 and not stub:
         out["batched"] = batched_throughput(args, c, dev, local_rank, world, backend)
+        if args.config == "C3" and not args.no_batch_sizes:
+            # the same measurement on smaller bases, of which more fit into HBM (the batch kernel is limited by the number
+            # of bases in flight): C4-size (50k) and C2-size (10k)
+            out["batched_other_sizes"] = [
+                batched_throughput(args, dict(CONFIGS["C4"]), dev, local_rank, world, backend, B=3072, cfg_name="C4"),
+                batched_throughput(args, dict(CONFIGS["C2"]), dev, local_rank, world, backend, B=4096, cfg_name="C2")]
     if rank == 0 and not args.no_cpu_baseline:
         c0 = CONFIGS[args.config]
         cp0, ri0, v0 = (cp, ri, v) if c["seed"] == c0["seed"] else backend.gen_lp_basis(c0["m"], c0["k"], c0["bw"], c0["tri_frac"], c0["seed"], c0["offscale"])

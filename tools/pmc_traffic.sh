@@ -11,7 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   out=$R/gpurun_out/pmc_$c
   rm -rf $out; mkdir -p $out
   timeout -k 10 500 rocprofv3 --pmc $c --kernel-include-regex k_pivot_loop -d $out -o pmc --output-format csv -- \
-      python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --batch $BATCH > $out/run.log 2>&1
+      python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-batch-sizes --batch $BATCH > $out/run.log 2>&1
   rc=$?
   # (rocprofv3 of this image sometimes dumps core in its exit handler AFTER the result files are written: the pass
   # counts if the counter file is there)
@@ -23,7 +23,7 @@ import sys, glob, csv, json, collections, os
 R, BATCH = sys.argv[1], int(sys.argv[2])
 sys.path.insert(0, R)
 import bench
-tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(R + "/gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
@@ -31,9 +31,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = ("k_pivot_loop_wave" if "k_pivot_loop_wave" in kn else "k_pivot_loop_batch" if "k_pivot_loop_batch" in kn
                  else ("k_pivot_loop" if "k_pivot_loop" in kn else None))
             if k and r["Counter_Name"] == c:
-                tot[k][c] += float(r["Counter_Value"]); n[k][c] += 1
+                vals[k][c].append(float(r["Counter_Value"]))
+# per launch: the FULL launches only -- the warm-up repetition of a batch relaunches the kernel after storage growth
+# (ST_NEED_*), and such partial launches would pull an average down
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+for k in vals:
+    for c in vals[k]:
+        full = [v for v in vals[k][c] if v >= 0.8 * max(vals[k][c])]
+        tot[k][c] = sum(full); n[k][c] = len(full)
 rec = {"kernel_source_sha16": bench.kernel_source_sha16(),
-       "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-include-regex k_pivot_loop -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --batch %d" % BATCH,
+       "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-include-regex k_pivot_loop -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-batch-sizes --batch %d" % BATCH,
        "note": "FETCH_SIZE/WRITE_SIZE are reported in KB.  FETCH_SIZE is NOT doubled: the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide "
                "(16 B/lane) coalesced streams; these kernels issue scattered 4- and 8-byte accesses -- see `calibration` (tools/pmc_calib.sh: what "
                "the counters report for known-byte scattered gathers / scatters and for a 16-byte stream on this box).  Infinity-Cache hits are "
