@@ -67,25 +67,31 @@ __device__ __forceinline__ void wv_hinsert(Fast *fa, int k, int v)
     }
     wv_probe_overrun(__LINE__);
 }
-// value of key k, -1 if absent: the first two probes in straight-line code (the table is at most half full)
+// value of key k, -1 if absent.  The first two probes are read TOGETHER (one LDS round trip; the table is at most
+// half full, so they decide practically every look-up) and combined without a branch; a third probe is rare.
 __device__ __forceinline__ int wv_hfind(const Fast *fa, int k)
 {
     const unsigned s0 = wv_hslot(k), s1 = (s0 + 1) & (WV_HASH - 1);
     const unsigned long long x0 = fa->hsh[s0], x1 = fa->hsh[s1];
     const bool h0 = (int)(x0 >> 32) == k, e0 = x0 == ~0ull, h1 = (int)(x1 >> 32) == k, e1 = x1 == ~0ull;
-    if (h0) return (int)(x0 & 0xffffffffull);
-    if (e0) return -1;
-    if (h1) return (int)(x1 & 0xffffffffull);
-    if (e1) return -1;
-    unsigned s = (s1 + 1) & (WV_HASH - 1);
-    for (int n = 2; n < WV_HASH; n++) {
-        const unsigned long long x = fa->hsh[s];
-        if ((int)(x >> 32) == k) return (int)(x & 0xffffffffull);
-        if (x == ~0ull) return -1;
-        s = (s + 1) & (WV_HASH - 1);
+    int r = h0 ? (int)(x0 & 0xffffffffull) : ((!e0 && h1) ? (int)(x1 & 0xffffffffull) : -1);
+    if (!(h0 || e0 || h1 || e1)) { // both slots taken by other keys: go on probing
+        unsigned s = (s1 + 1) & (WV_HASH - 1);
+        r = -1;
+        bool found = false;
+        for (int n = 2; n < WV_HASH && !found; n++) {
+            const unsigned long long x = fa->hsh[s];
+            if ((int)(x >> 32) == k) {
+                r = (int)(x & 0xffffffffull);
+                found = true;
+            } else if (x == ~0ull) {
+                found = true;
+            }
+            s = (s + 1) & (WV_HASH - 1);
+        }
+        if (!found) wv_probe_overrun(__LINE__);
     }
-    wv_probe_overrun(__LINE__);
-    return -1;
+    return r;
 }
 
 // exclusive prefix sum over the wave; *total = sum
@@ -425,6 +431,7 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, Wv
     }
     const long long tboth = wave_sum_ll(((long long)L.cl << 32) | (long long)(unsigned)L.rl);
     if ((tboth >> 32) > WV_TMAX || (tboth & 0xffffffffLL) > WV_TMAX) kind = 0;
+    if (D.carena_cap >= (1 << 29) || D.rarena_cap >= (1 << 29)) kind = 0; // (32-bit byte offsets into the arenas: wv_ld / wv_st)
     if (kind == 1) {
         const long long both = wave_sum_ll((gc << 32) | (gr & 0xffffffffLL));
         if ((long long)sm->cused + (both >> 32) > (long long)D.carena_cap || (long long)sm->rused + (both & 0xffffffffLL) > (long long)D.rarena_cap)
@@ -599,6 +606,18 @@ __device__ __forceinline__ int wv_rank(const WvSeg &sg, unsigned long long kb, i
     return wave_prefix_count(kb) - __popcll(kb & sg.below_h) + (sg.first_seg ? carry : 0);
 }
 
+// Arena accesses of the passes with a 32-bit BYTE offset from the (scalar) array base: `global_load v, v_off, s[base]`
+// instead of a 64-bit address built per lane (sign extension + two 64-bit shift-adds per access).  The flattened
+// paths are taken only while the arenas are below 2^29 entries (wv_layout), so the offsets fit.
+template <class T> __device__ __forceinline__ T wv_ld(GPTR(const T) base, int i)
+{
+    return *(GPTR(const T))((GPTR(const char))base + (unsigned)i * (unsigned)sizeof(T));
+}
+template <class T> __device__ __forceinline__ void wv_st(GPTR(T) base, int i, T v)
+{
+    *(GPTR(T))((GPTR(char))base + (unsigned)i * (unsigned)sizeof(T)) = v;
+}
+
 // One pass of a flattened phase, loads issued: which line each lane is in, the entry it holds.  The passes are
 // software-pipelined -- pass k+1 is fetched before pass k is worked on -- because a wave alone on its matrix has
 // nothing else to hide a memory round trip behind, and a small pivot has ~16 such passes.  (The in-place stores of
@@ -626,13 +645,12 @@ __device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idx
     P.valid = f < T;
     P.sg = wv_segment(hw, cbv, P.valid, f == T - 1);
     cbv += __popcll(hw);
-    P.bo = fa->sBO[P.valid ? P.sg.c : 0];
+    P.bo = fa->sBO[P.sg.c]; // (a lane past the end: the slot of the last line -- a valid slot, its entry is not used)
     P.e = f + f0 - P.bo.y;
     const int pos = P.valid ? P.bo.x + P.e : 0;
-    P.idx = idxarr[pos];
+    P.idx = wv_ld<int>(idxarr, pos);
     P.val = 0.0;
-    if (VALUES) P.val = D.cval[pos];
-    if (!P.valid) P.idx = -1;
+    if (VALUES) P.val = wv_ld<double>(D.cval, pos);
     return P;
 }
 
@@ -716,8 +734,8 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
                     fa->sK0i[sg.c] = idx;
                     fa->sK0v[sg.c] = val;
                 } else {
-                    D.cidx[bo.x + t - 1] = idx;
-                    D.cval[bo.x + t - 1] = val;
+                    wv_st<int>(D.cidx, bo.x + t - 1, idx);
+                    wv_st<double>(D.cval, bo.x + t - 1, val);
                 }
                 atomicMax(&fa->sMax[sg.c], (unsigned long long)__double_as_longlong(fabs(val)));
             }
@@ -794,8 +812,8 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             const unsigned long long kxb = __ballot(kx);
             if (kx) {
                 const int rank = wave_prefix_count(kxb) - __popcll(kxb & segbelow);
-                D.cidx[dd + rank] = pi_l;
-                D.cval[dd + rank] = x;
+                wv_st<int>(D.cidx, dd + rank, pi_l);
+                wv_st<double>(D.cval, dd + rank, x);
                 atomicMax(&fa->sMax[c], (unsigned long long)__double_as_longlong(ax));
             }
             if (act && p_l == 0) {
@@ -867,7 +885,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             const int t = valid ? wv_rank(sg, kb, carry) : 0;
             carry = __builtin_amdgcn_readlane(t + (keep ? 1 : 0), 63);
             if (sg.tail) fa->sCnt[sg.c] = t + (keep ? 1 : 0);
-            if (keep && t != P.e) D.ridx[P.bo.x + t] = j;
+            if (keep && t != P.e) wv_st<int>(D.ridx, P.bo.x + t, j);
         };
         const int npass = (Tr + 63) >> 6;
         WvPass PA = wv_fetch<false>(D, fa, D.ridx, 0, Tr, 0, cbv), PB = PA;
@@ -942,7 +960,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
             const unsigned long long okb = __ballot(ok);
             if (ok) {
                 const int rank = wave_prefix_count(okb) - __popcll(okb & rsegbelow);
-                D.ridx[fa->sDst[p] + rank] = tj_l;
+                wv_st<int>(D.ridx, fa->sDst[p] + rank, tj_l);
             }
             if (anycb && act && q_l == 0) fa->sNew[p] = __popcll(okb & rsegmask);
         }

@@ -15,7 +15,7 @@ timeout -k 10 300 python bench.py --config C5 --steps 1 --warmup 0 > $E/bench_c5
 echo "benches done"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof_c3 -o c3 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --batch 0 --no-cpu-baseline > $E/prof_c3.log 2>&1 )
 find $E/prof_c3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $E/c3_kernel_stats.csv
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof_b3 -o b3 --output-format csv -- python3 $R/tools/batch_probe.py 1536 256 C3 1 > $E/prof_b3.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof_b3 -o b3 --output-format csv -- python3 $R/tools/batch_probe.py 1536 256 C3 2 > $E/prof_b3.log 2>&1 )
 find $E/prof_b3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $E/batch_c3_kernel_stats.csv
 echo "kernel stats done"
 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 1536 C3 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c3.txt

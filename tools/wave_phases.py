@@ -16,7 +16,7 @@ mats = []
 for s in range(nd):
     cp, ri, v = blu_amd.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], c["seed"] + s, c["offscale"])
     mats.append((torch.from_numpy(cp.view(np.int64)).to(dev), torch.from_numpy(ri.view(np.int64)).to(dev), torch.from_numpy(v).to(dev), len(ri)))
-hs = [blu_amd.BLU(c["m"], mats[k % nd][3]) for k in range(B)]
+hs = [blu_amd.BLU(c["m"], mats[k % nd][3] // 2) for k in range(B)]  # (the capacity hint bench.py uses)
 ptrs = [(mats[k % nd][0].data_ptr(), mats[k % nd][0].data_ptr() + 8, mats[k % nd][1].data_ptr(), mats[k % nd][2].data_ptr(), mats[k % nd][3]) for k in range(B)]
 for rep in range(2):
     st = blu_amd.factorize_batch(hs, device_ptrs=ptrs)
