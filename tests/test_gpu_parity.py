@@ -382,6 +382,26 @@ def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):
     assert a.stat(110) + a.stat(111) >= 0.8 * (a.stat(52) + a.stat(54)) and b.stat(110) == 0  # (pivot rows beyond 64 entries: general paths)
 
 
+def test_canonical_factors_inside_the_arena_and_in_their_own_buffers(blu, oracle, monkeypatch):
+    """get_factors reads the canonical L / U from inside the (dead) column arena when they fit (ensure_out) and from
+    buffers of their own otherwise (forced here with BLU_NO_OUT_ALIAS, read when the handle is created): same factors
+    either way, also after a second factorize of another matrix on the same handles and after solves."""
+    cp, ri, v = oracle.gen_lp_basis(2500, 10, 9, 0.5, 3, 0.3)
+    cp2, ri2, v2 = oracle.gen_lp_basis(2500, 7, 12, 0.3, 8, 0.5)
+    a = blu.BLU(2500, len(ri))
+    monkeypatch.setenv("BLU_NO_OUT_ALIAS", "1")
+    b = blu.BLU(2500, len(ri))
+    monkeypatch.delenv("BLU_NO_OUT_ALIAS")
+    for (c, r, x) in ((cp, ri, v), (cp2, ri2, v2), (cp, ri, v)):
+        assert a.factorize(c[:-1], c[1:], r, x) == b.factorize(c[:-1], c[1:], r, x) == K.OK
+        o, so = util.oracle_factorize(oracle, c, r, x, allow_d3=True)
+        rhs = np.random.default_rng(1).standard_normal(2500)
+        assert np.array_equal(a.solve_dense(rhs, "N"), o.solve_dense(rhs, "N"))  # (the solves read the canonical U)
+        fa, fb, fo = a.get_factors(), b.get_factors(), o.get_factors()
+        for k in util.INT_KEYS + util.VAL_KEYS:
+            assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], fo[k]), k
+
+
 def test_general_paths_only_matches_fast_paths(blu, oracle):
     """A/B of the two implementations of the pivot loop (LDS fast paths on / off)."""
     cp, ri, v = oracle.gen_lp_basis(3000, 9, 10, 0.4, 17, 0.4)
