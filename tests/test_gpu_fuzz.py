@@ -131,3 +131,43 @@ def test_fuzz_slice_self_checking_library(args, tag):
     assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
     assert "self-checking build" in text, text[:300]  # (the child really ran on that library)
     assert tag in text
+
+
+# ---- the batch entry (blu_hip_factorize_batch -> k_pivot_loop_wave, one wave per basis): random batches of mixed sizes, and
+# slices of the single-matrix sweep with the one-wave kernel forced onto them (BLU_PIVOT_KERNEL=1, fresh seed)
+def _run_slice(cmd, log, what, env=None, timeout=400):
+    if _stop["why"]:
+        pytest.skip("not started: " + _stop["why"])
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        _stop["why"] = "%s hung; last case started: %s" % (what, _last_started(log))
+        pytest.fail(_stop["why"])
+    text = r.stdout.decode(errors="replace")
+    if r.returncode < 0 or r.returncode >= 124:
+        _stop["why"] = "%s was killed (rc %d); last case started: %s" % (what, r.returncode, _last_started(log))
+        pytest.fail(_stop["why"] + "\n" + text[-2000:])
+    assert r.returncode == 0, "first failing case: %s\n%s" % (_last_started(log), text[-3000:])
+    return text
+
+
+@pytest.mark.parametrize("start", [0, 15])
+def test_batch_fuzz_slice(start):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzzbatch_s2025_%04d.log" % start)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_batch_gpu.py"), "--seed", "2025", "--start", str(start), "--count", "15", "--log", log]
+    text = _run_slice(cmd, log, "batch slice %d" % start)
+    assert ("all 15 batches of seed 2025 from %d identical" % start) in text
+
+
+@pytest.mark.parametrize("args,tag", [(["--seed", "9090", "--start", "0", "--count", "150"], "all 150 cases of seed 9090 from 0 identical"),
+                                      (["--seed", "33", "--start", "0", "--count", "15", "--mmin", "1500", "--mmax", "9000"],
+                                       "all 15 cases of seed 33 from 0 identical")], ids=["small", "mid"])
+def test_fuzz_slice_one_wave_kernel_forced(args, tag):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzz_wave_s%s.log" % args[1])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")] + args + ["--log", log]
+    text = _run_slice(cmd, log, "one-wave slice", env=dict(os.environ, BLU_PIVOT_KERNEL="1"))
+    assert tag in text
