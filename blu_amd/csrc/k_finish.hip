@@ -273,9 +273,12 @@ __global__ void __launch_bounds__(1024) k_finish_grid(DevLU *Ds, FinishOut *Os, 
 // ---------------------------------------------------------------------------------------------
 // k_compact: copy every line of one file into a new arena (which = 0 column file, 1 row file)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_compact(DevLU *Ds, int which, int *const *new_idx, double *const *new_val,
+// One workgroup per handle of the batch; whichv[b]: 0 = column file, 1 = row file, < 0 = nothing to do for handle b.
+__global__ void __launch_bounds__(1024) k_compact(DevLU *Ds, const int *whichv, int *const *new_idx, double *const *new_val,
                                                   const int *new_cap)
 {
+    const int which = whichv[blockIdx.x];
+    if (which < 0) return;
     const DevG D(Ds[blockIdx.x]);
     Scalars *S = D.s;
     __shared__ int sh[40];
