@@ -83,7 +83,8 @@ def cpu_baseline(cp, ri, v, label, budget_s=12.0, max_reps=12):
 
 def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=None):
     """SECONDARY measurement (never `value`): B independent bases of the same configuration in flight
-    on this GPU (blu_hip_factorize_batch), ONE WAVE per basis in the pivot kernel (k_pivot_loop_wave).  A
+    on this GPU (blu_hip_factorize_batch): one wave per basis in the pivot kernel (k_pivot_loop_wave), two while the card
+    holds no more than half the bases its registers would allow (k_pivot_loop_wave2: bases of the 100k size).  A
     single factorize is a chain of dependent pivots and can not use more than one CU; this is the mode in
     which the chip fills up.  8 distinct matrices (seeds) are cycled over the B handles; inputs resident in HBM."""
     import numpy as np
@@ -113,6 +114,7 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
         if rep > 0 and (best is None or el < best[0]):
             F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs)
             lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
+            which = int(hs[0].stat(118))  # the pivot kernel the library chose (blu_driver.inc: batch_pivot_and_finish)
             best = (el, hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP), int(hs[0].stat(K.STAT_DEV_RELAUNCHES)), F, lu,
                     [hs[0].stat(k) for k in (44, 45, 46, 47)],
                     (hs[0].stat(110) + hs[0].stat(111)) / max(1.0, hs[0].stat(52) + hs[0].stat(54)))
@@ -122,12 +124,12 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
     for h in hs:
         h.close()
     traffic = None
-    wave = os.environ.get("BLU_PIVOT_KERNEL", "0") in ("0", "1")
-    kname = "k_pivot_loop_wave" if wave else "k_pivot_loop_batch"
+    kname = {0: "k_pivot_loop", 1: "k_pivot_loop_wave", 2: "k_pivot_loop_batch", 3: "k_pivot_loop_wave2"}[which]
+    wg_threads = {0: args.batch_block, 1: 64, 2: args.batch_block, 3: 128}[which]
     tinfo = _traffic_record(kname)
     if tinfo and tinfo.get("bases") == B and tinfo.get("config") == cfg_name:
         traffic = tinfo["hbm_bytes_per_launch"] / max(t_piv / max(nl, 1), 1e-12) / 1e9
-    return {"config": "%s-size bases (m = %d)" % (cfg_name, c["m"]), "bases_in_flight_per_gpu": B, "workgroup_threads": 64 if wave else args.batch_block, "nnz_per_s": world * nnz / el,
+    return {"config": "%s-size bases (m = %d)" % (cfg_name, c["m"]), "bases_in_flight_per_gpu": B, "workgroup_threads": wg_threads, "nnz_per_s": world * nnz / el,
             "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
             "phases_seconds": {"k_prep": hs_phase[0], "k_setup": hs_phase[1], "k_finish": hs_phase[2], "k_stats": hs_phase[3]},
             "flattened_path_share": fast_share,

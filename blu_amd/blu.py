@@ -336,7 +336,8 @@ class BLU:
             raise BluError(st)
 
     def dbg_set_pivot_kernel(self, which):
-        """0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = one wave per matrix, 2 = multi-wave workgroups"""
+        """0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave2 while every workgroup is resident, else
+        k_pivot_loop_wave), 1 = one wave per matrix, 2 = multi-wave workgroups, 3 = two waves per matrix"""
         lib().blu_hip_dbg_set_pivot_kernel.argtypes = [C.c_void_p, C.c_int]
         st = lib().blu_hip_dbg_set_pivot_kernel(self._h, int(which))
         if st != K.OK:

@@ -240,6 +240,18 @@ __device__ __forceinline__ void wave_mem_sync(const char *f = __builtin_FILE(), 
 #else
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 #endif
+// A workgroup barrier that orders LDS only: the waves meet once each has its LDS operations behind it; its global
+// stores may still be in flight unless `drain` (a per-wave choice: only a wave whose stores another wave will load has
+// to wait for them).  __syncthreads() drains every wave's global stores, ~1-2 k cycles the waves mostly do not owe.
+#ifdef BLU_EMU_BUILD
+__device__ __forceinline__ void wg_barrier_lds(bool) { __syncthreads(); }
+#else
+__device__ __forceinline__ void wg_barrier_lds(bool drain)
+{
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif
 // The lanes of a wave execute every instruction together: "lane A loads X, then lane B stores X" needs nothing on
 // the GPU.  The CPU emulation build (emu/hip/hip_runtime.h) runs the lanes of a wave one after the other between two
 // collectives; WAVE_LOCKSTEP() marks the places that rely on lockstep and is a wave barrier there, nothing here.

@@ -36,9 +36,17 @@
 #undef BLU_NS
 #undef BLU_CFG_BATCH
 #undef BLU_CFG_WAVE
+#define BLU_NS pv_wave2
+#define BLU_CFG_BATCH 1
+#define BLU_CFG_WAVE 2
+#include "k_pivot.hip"
+#undef BLU_NS
+#undef BLU_CFG_BATCH
+#undef BLU_CFG_WAVE
 using pv_single::k_pivot_loop;
 using pv_batch::k_pivot_loop_batch;
 using pv_wave::k_pivot_loop_wave;
+using pv_wave2::k_pivot_loop_wave2;
 #include "k_prep.hip"
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"
@@ -68,7 +76,7 @@ struct blu_hip {
     int batch_block;   // workgroup size of the pivot kernel when this handle leads a batch
     int batch_block_other, batch_block_stats; // workgroup sizes of k_prep / k_setup / k_finish and of k_stats in a batch
     int no_out_alias;  // diagnostic: 1 = canonical factors always in buffers of their own (see ensure_out)
-    int pivot_kernel;  // 0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave), 1 = k_pivot_loop_wave, 2 = the multi-wave kernels
+    int pivot_kernel;  // 0 = default (one basis: k_pivot_loop; batch: k_pivot_loop_wave2 while all its workgroups are resident, else k_pivot_loop_wave), 1 = k_pivot_loop_wave, 2 = the multi-wave kernels, 3 = k_pivot_loop_wave2
     int64_t out_lcap, out_ucap;
     bool out_in_arena; // the canonical L / U of the last factorize live inside the (then dead) column arena, not in buffers of their own
     // owned device copies of the caller's B (blu_hip_factorize with host arrays)
@@ -113,6 +121,8 @@ struct blu_hip {
     int skip_stats;    // 1: do not compute condest / residual_test inside factorize (keys return 0)
     GridWs *gw;        // scratch of the chip-wide O(nnz) phases (single-basis path)
     int grid_blocks;   // workgroups of their cooperative launches (0/1: one workgroup, as in a batch)
+    int last_pivot_kernel;
+    int wave2_max;     // bases the card holds at once with TWO waves each (k_pivot_loop_wave2): a batch up to this size takes that kernel
     std::string err;
     int64_t stop_at;   // debug: -1 off
 };
@@ -320,7 +330,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         h->no_out_alias = getenv("BLU_NO_OUT_ALIAS") ? 1 : 0;
         const char *pk = getenv("BLU_PIVOT_KERNEL");
         h->pivot_kernel = pk ? atoi(pk) : 0;
-        if (h->pivot_kernel < 0 || h->pivot_kernel > 2) h->pivot_kernel = 0;
+        if (h->pivot_kernel < 0 || h->pivot_kernel > 3) h->pivot_kernel = 0;
     }
     if (ok) { // chip-wide phases: as many workgroups as are certainly co-resident, at most 64 (one per CU of two XCDs' worth)
         int nb = 0, best = 1 << 30;
@@ -331,6 +341,8 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         }
         h->grid_blocks = std::max(1, std::min(best, 64));
         if (!prop.cooperativeLaunch) h->grid_blocks = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave2, 128, 0) != hipSuccess) nb = 0;
+        h->wave2_max = nb * prop.multiProcessorCount;
         // the chain kernels keep ~106 KB of LDS rings per workgroup (k_chain.h)
         h->chain_ok = h->grid_blocks > 1 && (size_t)prop.sharedMemPerBlock >= sizeof(ChainLds) &&
                       hipFuncSetAttribute((const void *)k_stats_chains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainLds)) == hipSuccess &&
@@ -480,6 +492,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 113: return (double)s.rused;
     case 114: return (double)h->D.carena_cap;
     case 115: return (double)h->D.lcap;
+    case 118: return (double)h->last_pivot_kernel; // which pivot kernel the last factorize of this handle ran: 0 k_pivot_loop, 1 k_pivot_loop_wave, 2 k_pivot_loop_batch, 3 k_pivot_loop_wave2
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
     case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:
@@ -548,59 +561,78 @@ static bool compact_files(blu_hip *const *hs, int n, DevLU *slots, hipStream_t s
     std::vector<double *> nval(n, nullptr);
     std::vector<int> ncap(n, 0), which(n, -1);
     ok.assign(n, 1);
-    bool any = false;
-    for (int k = 0; k < n; k++) {
-        if (req[k] < 0) continue;
-        blu_hip *h = hs[k];
-        DevLU &D = h->D;
-        const int64_t oldcap = req[k] ? D.rarena_cap : D.carena_cap;
-        const int64_t nn = grown(h, oldcap, need[k]);
-        if (nn <= oldcap) { h->err = "arena limit (2^31 entries) reached"; ok[k] = 0; continue; }
-        if (!dalloc(h, &nidx[k], (size_t)nn) || (!req[k] && !dalloc(h, &nval[k], (size_t)nn))) {
-            dfree(nidx[k]);
-            ok[k] = 0;
-            continue;
-        }
-        ncap[k] = (int)nn;
-        which[k] = req[k];
-        any = true;
-    }
-    if (!any) return true;
     int **d_pi = nullptr;
     double **d_pv = nullptr;
     int *d_cap = nullptr, *d_which = nullptr;
-    bool good = dalloc(h0, &d_pi, n) && dalloc(h0, &d_pv, n) && dalloc(h0, &d_cap, n) && dalloc(h0, &d_which, n) &&
-                hip_ok(h0, hipMemcpy(d_pi, nidx.data(), sizeof(int *) * n, hipMemcpyHostToDevice), "h2d arenas") &&
-                hip_ok(h0, hipMemcpy(d_pv, nval.data(), sizeof(double *) * n, hipMemcpyHostToDevice), "h2d arenas") &&
-                hip_ok(h0, hipMemcpy(d_cap, ncap.data(), sizeof(int) * n, hipMemcpyHostToDevice), "h2d arenas") &&
-                hip_ok(h0, hipMemcpy(d_which, which.data(), sizeof(int) * n, hipMemcpyHostToDevice), "h2d arenas");
-    if (good) {
-        hipLaunchKernelGGL(k_compact, dim3(n), dim3(1024), 0, stream, slots, d_which, d_pi, d_pv, d_cap);
-        good = hip_ok(h0, hipStreamSynchronize(stream), "k_compact");
+    bool good = true;
+    // Old and new arena of a handle exist side by side until its files are moved: a batch that fills the card (3072 bases
+    // of the 50k size) cannot have that for all its handles at once.  So: rounds, each as many handles as fit in most of
+    // the memory that is free now.
+    for (int start = 0; start < n && good;) {
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = 0;
+        const size_t budget = freeb - freeb / 4;
+        size_t used = 0;
+        bool any = false;
+        int k = start;
+        std::fill(which.begin(), which.end(), -1);
+        for (; k < n; k++) {
+            if (req[k] < 0) continue;
+            blu_hip *h = hs[k];
+            DevLU &D = h->D;
+            const int64_t oldcap = req[k] ? D.rarena_cap : D.carena_cap;
+            const int64_t nn = grown(h, oldcap, need[k]);
+            if (nn <= oldcap) { h->err = "arena limit (2^31 entries) reached"; ok[k] = 0; continue; }
+            const size_t bytes = (size_t)nn * (req[k] ? sizeof(int) : sizeof(int) + sizeof(double));
+            if (any && used + bytes > budget) break; // the next round (a round takes one handle at least)
+            if (!dalloc(h, &nidx[k], (size_t)nn) || (!req[k] && !dalloc(h, &nval[k], (size_t)nn))) {
+                dfree(nidx[k]);
+                nidx[k] = nullptr;
+                ok[k] = 0;
+                continue;
+            }
+            used += bytes;
+            ncap[k] = (int)nn;
+            which[k] = req[k];
+            any = true;
+        }
+        const int end = k;
+        if (any) {
+            good = (d_pi || (dalloc(h0, &d_pi, n) && dalloc(h0, &d_pv, n) && dalloc(h0, &d_cap, n) && dalloc(h0, &d_which, n))) &&
+                   hip_ok(h0, hipMemcpy(d_pi, nidx.data(), sizeof(int *) * n, hipMemcpyHostToDevice), "h2d arenas") &&
+                   hip_ok(h0, hipMemcpy(d_pv, nval.data(), sizeof(double *) * n, hipMemcpyHostToDevice), "h2d arenas") &&
+                   hip_ok(h0, hipMemcpy(d_cap, ncap.data(), sizeof(int) * n, hipMemcpyHostToDevice), "h2d arenas") &&
+                   hip_ok(h0, hipMemcpy(d_which, which.data(), sizeof(int) * n, hipMemcpyHostToDevice), "h2d arenas");
+            if (good) {
+                hipLaunchKernelGGL(k_compact, dim3(n), dim3(1024), 0, stream, slots, d_which, d_pi, d_pv, d_cap);
+                good = hip_ok(h0, hipStreamSynchronize(stream), "k_compact");
+            }
+            for (int q = start; q < end; q++) {
+                if (which[q] < 0) continue;
+                blu_hip *h = hs[q];
+                DevLU &D = h->D;
+                if (!good) {
+                    dfree(nidx[q]); dfree(nval[q]);
+                    ok[q] = 0;
+                    continue;
+                }
+                if (which[q]) {
+                    dfree(D.ridx);
+                    D.ridx = nidx[q];
+                    D.rarena_cap = ncap[q];
+                } else {
+                    dfree(D.cidx);
+                    dfree(D.cval);
+                    D.cidx = nidx[q];
+                    D.cval = nval[q];
+                    D.carena_cap = ncap[q];
+                }
+                if (!upload_desc(h)) ok[q] = 0;
+            }
+        }
+        start = end;
     }
     dfree(d_pi); dfree(d_pv); dfree(d_cap); dfree(d_which);
-    for (int k = 0; k < n; k++) {
-        if (which[k] < 0) continue;
-        blu_hip *h = hs[k];
-        DevLU &D = h->D;
-        if (!good) {
-            dfree(nidx[k]); dfree(nval[k]);
-            ok[k] = 0;
-            continue;
-        }
-        if (which[k]) {
-            dfree(D.ridx);
-            D.ridx = nidx[k];
-            D.rarena_cap = ncap[k];
-        } else {
-            dfree(D.cidx);
-            dfree(D.cval);
-            D.cidx = nidx[k];
-            D.cval = nval[k];
-            D.carena_cap = ncap[k];
-        }
-        if (!upload_desc(h)) ok[k] = 0;
-    }
     return good;
 }
 
@@ -931,10 +963,11 @@ extern "C" int blu_hip_dbg_set_grid_blocks(blu_hip *h, int nblocks)
     h->grid_blocks = nblocks;
     return BLU_OK;
 }
-// 0 = default, 1 = one wave per matrix (k_pivot_loop_wave), 2 = multi-wave workgroups (k_pivot_loop / k_pivot_loop_batch)
+// 0 = default, 1 = one wave per matrix (k_pivot_loop_wave), 2 = multi-wave workgroups (k_pivot_loop / k_pivot_loop_batch),
+// 3 = two waves per matrix (k_pivot_loop_wave2)
 extern "C" int blu_hip_dbg_set_pivot_kernel(blu_hip *h, int which)
 {
-    if (!h || which < 0 || which > 2) return BLU_ERROR_INVALID_ARGUMENT;
+    if (!h || which < 0 || which > 3) return BLU_ERROR_INVALID_ARGUMENT;
     h->pivot_kernel = which;
     return BLU_OK;
 }

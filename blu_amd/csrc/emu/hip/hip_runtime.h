@@ -292,6 +292,7 @@ template <class T> inline hipError_t hipMalloc(T **p, size_t bytes)
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)1 << 34; *t = (size_t)1 << 35; return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }

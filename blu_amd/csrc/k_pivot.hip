@@ -100,7 +100,7 @@ struct alignas(16) Sm {
     int sh[40];
     long long shl[20];
 #if BLU_CFG_WAVE
-    unsigned long long wmax[1];
+    unsigned long long wmax[BLU_CFG_WAVE]; // (one or two waves per matrix)
 #else
     unsigned long long wmax[16]; // per wave: maximum of a line through an LDS atomic, zero between uses
 #endif

@@ -30,7 +30,7 @@
 #ifdef BLU_PROFILE
 #define WV_T(k)                                                                \
     do {                                                                       \
-        if (lane_id() == 0) {                                                  \
+        if (threadIdx.x == 0) {                                                \
             const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
             sm->prof[k] += t_ - g_pstamp[0];                                   \
             sm->prof[24 + (k)] += 1;                                           \
@@ -50,18 +50,18 @@ __device__ __forceinline__ void wv_probe_overrun(int line)
     g_pivot_err_line = line;
 }
 // every lane: empty the table (two words per lane)
-__device__ __forceinline__ void wv_hclear(Fast *fa)
+__device__ __forceinline__ void wv_hclear_t(unsigned long long *tab)
 {
     const int lane = lane_id();
-    fa->hsh[lane] = ~0ull;
-    fa->hsh[lane + 64] = ~0ull;
+    tab[lane] = ~0ull;
+    tab[lane + 64] = ~0ull;
 }
-__device__ __forceinline__ void wv_hinsert(Fast *fa, int k, int v)
+__device__ __forceinline__ void wv_hinsert_t(unsigned long long *tab, int k, int v)
 {
     unsigned s = wv_hslot(k);
     const unsigned long long want = ((unsigned long long)(unsigned)k << 32) | (unsigned)v;
     for (int n = 0; n < WV_HASH; n++) {
-        const unsigned long long old = atomicCAS(&fa->hsh[s], ~0ull, want);
+        const unsigned long long old = atomicCAS(&tab[s], ~0ull, want);
         if (old == ~0ull || (int)(old >> 32) == k) return;
         s = (s + 1) & (WV_HASH - 1);
     }
@@ -69,10 +69,10 @@ __device__ __forceinline__ void wv_hinsert(Fast *fa, int k, int v)
 }
 // value of key k, -1 if absent.  The first two probes are read TOGETHER (one LDS round trip; the table is at most
 // half full, so they decide practically every look-up) and combined without a branch; a third probe is rare.
-__device__ __forceinline__ int wv_hfind(const Fast *fa, int k)
+__device__ __forceinline__ int wv_hfind_t(const unsigned long long *tab, int k)
 {
     const unsigned s0 = wv_hslot(k), s1 = (s0 + 1) & (WV_HASH - 1);
-    const unsigned long long x0 = fa->hsh[s0], x1 = fa->hsh[s1];
+    const unsigned long long x0 = tab[s0], x1 = tab[s1];
     const bool h0 = (int)(x0 >> 32) == k, e0 = x0 == ~0ull, h1 = (int)(x1 >> 32) == k, e1 = x1 == ~0ull;
     int r = h0 ? (int)(x0 & 0xffffffffull) : ((!e0 && h1) ? (int)(x1 & 0xffffffffull) : -1);
     if (!(h0 || e0 || h1 || e1)) { // both slots taken by other keys: go on probing
@@ -80,7 +80,7 @@ __device__ __forceinline__ int wv_hfind(const Fast *fa, int k)
         r = -1;
         bool found = false;
         for (int n = 2; n < WV_HASH && !found; n++) {
-            const unsigned long long x = fa->hsh[s];
+            const unsigned long long x = tab[s];
             if ((int)(x >> 32) == k) {
                 r = (int)(x & 0xffffffffull);
                 found = true;
@@ -93,6 +93,9 @@ __device__ __forceinline__ int wv_hfind(const Fast *fa, int k)
     }
     return r;
 }
+__device__ __forceinline__ void wv_hclear(Fast *fa) { wv_hclear_t(fa->hsh); }
+__device__ __forceinline__ void wv_hinsert(Fast *fa, int k, int v) { wv_hinsert_t(fa->hsh, k, v); }
+__device__ __forceinline__ int wv_hfind(const Fast *fa, int k) { return wv_hfind_t(fa->hsh, k); }
 
 // exclusive prefix sum over the wave; *total = sum
 __device__ __forceinline__ int wv_excl_scan(int v, int *total)
@@ -309,6 +312,45 @@ __device__ __forceinline__ void ew_step(const DevGP &D, Sm *sm, WvWalk &E, int K
     }
 }
 
+#if WV_NW == 2
+// Two waves per matrix: what the search (wave 0) found goes to LDS for both waves -- the metadata of every line of the
+// pivot, both membership tables, and which lines each wave takes (by weight: entries to read + entries to append).
+#ifndef WV2_SHARE0
+#define WV2_SHARE0 50 // percent of the columns' weight wave 0 takes (wave 1 then has all the rows)
+#endif
+__device__ __forceinline__ void wv2_publish(Fast *fa, const WvLines &L, int rnz1, int cnz1)
+{
+    const int lane = lane_id();
+    wv_hclear_t(fa->hshr); // (the table of the columns, fa->hsh: built by wave 1, wv2_small)
+    wave_mem_sync();
+    if (lane <= rnz1) {
+        fa->lJ[lane] = L.j;
+        fa->lFl[lane] = L.fl;
+        fa->lBl[lane] = L.bl;
+    }
+    if (lane < rnz1) {
+        fa->lCb[lane] = L.cb;
+        fa->lCl[lane] = L.cl;
+        fa->lCap[lane] = L.cap;
+    }
+    if (lane < cnz1) {
+        wv_hinsert_t(fa->hshr, L.i, lane);
+        fa->lI[lane] = L.i;
+        fa->lRb[lane] = L.rb;
+        fa->lRl[lane] = L.rl;
+        fa->lRc[lane] = L.rc;
+    }
+    // a line goes to wave 0 if it BEGINS inside wave 0's share (the first line always does)
+    int tc;
+    const int cw = wv_excl_scan(lane < rnz1 ? L.cl + cnz1 : 0, &tc);
+    const int cs = __popcll(__ballot(lane < rnz1 && (long long)cw * 100 < (long long)tc * WV2_SHARE0));
+    if (lane == 0) {
+        fa->csplit = cs;
+        fa->tiny = 0;
+    }
+}
+#endif
+
 // Second half of the search: room in L and U, the kind of pivot, and -- for the two flattened kinds -- the pivot row
 // (and column) in slot order with the metadata of every line they touch.  pv1 = the pivot value of a column singleton.
 __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, WvPick &P, int pc, int pr, int nzc, int pcb, int nzr, int prb, int where,
@@ -438,6 +480,9 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, Wv
             kind = 0; // the general path makes the exact check and leaves with NEED_CW / NEED_RW
     }
     WV_T(5);
+#if WV_NW == 2
+    if (kind == 1) wv2_publish(fa, L, rnz1, cnz1);
+#endif
     if (lane == 0) {
         fa->kind = kind;
         fa->where = wpos;
@@ -633,19 +678,19 @@ struct WvPass {
 // the arena): with a fixed number of loads in flight the compiler waits for "all but the newest two" when pass k is
 // worked on; loads under a branch would make it wait for everything, i.e. for the pass just fetched.
 template <bool VALUES>
-__device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idxarr, int k, int T, int f0, int &cbv)
+__device__ __forceinline__ WvPass wv_fetch_z(const DevGP &D, Fast *fa, unsigned long long *zw, const int2 *sbo, gcint_p idxarr, int k, int T, int f0, int &cbv)
 {
     const int lane = lane_id();
     WvPass P;
     const int kw = k < WV_ZW ? k : WV_ZW - 1; // (a call past the last pass: a word that is zero already)
-    const unsigned long long hw = fa->zw[kw];
+    const unsigned long long hw = zw[kw];
     WAVE_LOCKSTEP();
-    if (lane == 0) fa->zw[kw] = 0ull;
+    if (lane == 0) zw[kw] = 0ull;
     const int f = k * 64 + lane;
     P.valid = f < T;
     P.sg = wv_segment(hw, cbv, P.valid, f == T - 1);
     cbv += __popcll(hw);
-    P.bo = fa->sBO[P.sg.c]; // (a lane past the end: the slot of the last line -- a valid slot, its entry is not used)
+    P.bo = sbo[P.sg.c]; // (a lane past the end: the slot of the last line -- a valid slot, its entry is not used)
     P.e = f + f0 - P.bo.y;
     const int pos = P.valid ? P.bo.x + P.e : 0;
     P.idx = wv_ld<int>(idxarr, pos);
@@ -653,7 +698,13 @@ __device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idx
     if (VALUES) P.val = wv_ld<double>(D.cval, pos);
     return P;
 }
+template <bool VALUES>
+__device__ __forceinline__ WvPass wv_fetch(const DevGP &D, Fast *fa, gcint_p idxarr, int k, int T, int f0, int &cbv)
+{
+    return wv_fetch_z<VALUES>(D, fa, fa->zw, fa->sBO, idxarr, k, T, f0, cbv);
+}
 
+#if WV_NW == 1
 // ------------------------------------------------------------------------------------------------
 // pivot_small (pivot.rs:460-833), pivot row of <= 64 entries
 // ------------------------------------------------------------------------------------------------
@@ -1021,6 +1072,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     if (WV_EARLY_WALK && (E.st == 1 || E.st == 2)) ew_step(D, sm, E, D.maxsearch);
     WV_T(16);
 }
+#endif // WV_NW == 1
 
 // ------------------------------------------------------------------------------------------------
 // pivot_singleton_col (pivot.rs:928-1025), pivot row of <= 64 entries: every column of the pivot row loses its
@@ -1164,6 +1216,9 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     WV_T(21);
 }
 
+#if WV_NW == 2
+#include "k_pivot_wave2.inc" // pivot_small dealt out to two waves, the pivot loop and kernel of that configuration
+#else
 // ------------------------------------------------------------------------------------------------
 // the pivot loop of one matrix on one wave: factorize_bump (factorize_bump.rs:12-49) + pivot() (pivot.rs:48-112)
 // ------------------------------------------------------------------------------------------------
@@ -1343,3 +1398,4 @@ __global__ void __launch_bounds__(64) BLU_WAVES_PER_EU(BLU_WAVE_OCC, BLU_WAVE_OC
     __shared__ Sm smem;
     pivot_loop_wave(Ds, stop_at, &smem);
 }
+#endif // WV_NW

@@ -78,6 +78,19 @@ def test_wave_kernel_on_the_cpu(emu_lib, spec):
     assert fast > spec[0] // 2  # most pivots took the flattened paths
 
 
+@pytest.mark.parametrize("spec", [(300, 8, 8, 0.5, 1, 0.3), (400, 6, 20, 0.2, 3, 1.0), (250, 11, 30, 0.0, 5, 0.1)], ids=["banded", "wide", "no-triangle"])
+def test_two_wave_kernel_on_the_cpu(emu_lib, spec):
+    """k_pivot_loop_wave2: the lines of a small pivot dealt out to two waves, LDS-only barriers between the phases, the
+    walk of the next search begun while the other wave updates the rows"""
+    fast = run_child(emu_lib, [spec], kernel=3)
+    assert fast > spec[0] // 2
+
+
+def test_two_wave_general_paths_on_the_cpu(emu_lib):
+    """the general pivot paths as a workgroup of two waves"""
+    assert run_child(emu_lib, [(220, 8, 8, 0.5, 1, 0.3)], kernel=3, no_fast=True) == 0
+
+
 def test_wave_kernel_batch_on_the_cpu(emu_lib):
     """the batch entry: three bases of different sizes, one wave each"""
     fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6)], kernel=0)

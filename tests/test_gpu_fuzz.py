@@ -171,3 +171,17 @@ def test_fuzz_slice_one_wave_kernel_forced(args, tag):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")] + args + ["--log", log]
     text = _run_slice(cmd, log, "one-wave slice", env=dict(os.environ, BLU_PIVOT_KERNEL="1"))
     assert tag in text
+
+
+@pytest.mark.parametrize("args,tag", [(["--seed", "9191", "--start", "0", "--count", "150"], "all 150 cases of seed 9191 from 0 identical"),
+                                      (["--seed", "34", "--start", "0", "--count", "15", "--mmin", "1500", "--mmax", "9000"],
+                                       "all 15 cases of seed 34 from 0 identical")], ids=["small", "mid"])
+def test_fuzz_slice_two_wave_kernel_forced(args, tag):
+    """the sweep with k_pivot_loop_wave2 forced for every basis (a batch takes it by itself only while every workgroup
+    is resident)"""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzz_wave2_s%s.log" % args[1])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")] + args + ["--log", log]
+    text = _run_slice(cmd, log, "two-wave slice", env=dict(os.environ, BLU_PIVOT_KERNEL="3"))
+    assert tag in text

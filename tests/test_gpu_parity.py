@@ -361,25 +361,29 @@ def test_batch_of_independent_bases(blu, oracle):
 @pytest.mark.parametrize("spec", [(3000, 9, 10, 0.4, 17, 0.4), (2500, 10, 9, 0.5, 1, 0.3), (1800, 6, 30, 0.1, 9, 1.0)],
                          ids=["mixed", "c3-like", "wide-band"])
 def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):
-    """A/B of the two pivot kernels on one basis -- k_pivot_loop_wave (one wave per matrix, flattened line updates: the
-    kernel of a batch) against k_pivot_loop (sixteen waves) -- and both against the oracle; the flattened paths must
-    have taken practically every small and singleton-column pivot."""
+    """A/B/C of the pivot kernels on one basis -- k_pivot_loop_wave (one wave per matrix, flattened line updates) and
+    k_pivot_loop_wave2 (the same passes dealt out to two waves; the walk of the next search begun early), the kernels
+    of a batch, against k_pivot_loop (sixteen waves) -- and all against the oracle; the flattened paths must have
+    taken practically every small and singleton-column pivot."""
     cp, ri, v = oracle.gen_lp_basis(*spec)
     m = spec[0]
-    a, b = blu.BLU(m, len(ri)), blu.BLU(m, len(ri))
+    a, b, c2 = blu.BLU(m, len(ri)), blu.BLU(m, len(ri)), blu.BLU(m, len(ri))
     a.dbg_set_pivot_kernel(1)
     b.dbg_set_pivot_kernel(2)
-    sa, sb = a.factorize(cp[:-1], cp[1:], ri, v), b.factorize(cp[:-1], cp[1:], ri, v)
+    c2.dbg_set_pivot_kernel(3)
+    sa, sb, sc = (h.factorize(cp[:-1], cp[1:], ri, v) for h in (a, b, c2))
     o, so = util.oracle_factorize(oracle, cp, ri, v, allow_d3=True)
-    assert sa == sb == so == K.OK
-    fa, fb, fo = a.get_factors(), b.get_factors(), o.get_factors()
+    assert sa == sb == sc == so == K.OK
+    fa, fb, fc, fo = a.get_factors(), b.get_factors(), c2.get_factors(), o.get_factors()
     for k in util.INT_KEYS + util.VAL_KEYS:
-        assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], fo[k]), k
+        assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], fo[k]) and np.array_equal(fc[k], fo[k]), k
     for c in util.COUNTERS:
-        assert a.stat(getattr(K, "STAT_" + c)) == b.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), c
+        assert a.stat(getattr(K, "STAT_" + c)) == b.stat(getattr(K, "STAT_" + c)) == c2.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), c
     for kind in range(6):
-        assert a.stat(51 + kind) == b.stat(51 + kind) == o.stat(51 + kind), kind
+        assert a.stat(51 + kind) == b.stat(51 + kind) == c2.stat(51 + kind) == o.stat(51 + kind), kind
     assert a.stat(110) + a.stat(111) >= 0.8 * (a.stat(52) + a.stat(54)) and b.stat(110) == 0  # (pivot rows beyond 64 entries: general paths)
+    assert (c2.stat(110), c2.stat(111)) == (a.stat(110), a.stat(111))
+    assert c2.stat(117) >= 0.9 * c2.stat(110) - 50  # the walk of the next search begun while the rows were being updated
 
 
 def test_canonical_factors_inside_the_arena_and_in_their_own_buffers(blu, oracle, monkeypatch):

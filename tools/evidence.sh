@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence in one GPU call (outputs under gpurun_out/ev/; copied into profiles/ afterwards):
 #   bench lines of C3 (default run, with the batched legs), C2, C4, C5; rocprofv3 kernel stats of the single C3 bench
-#   and of a C3 batch; the phase table and the SQ counters of k_pivot_loop_wave; FETCH/WRITE_SIZE calibration and the
+#   and of a C3 batch; the phase tables and the SQ counters of k_pivot_loop_wave / k_pivot_loop_wave2; FETCH/WRITE_SIZE calibration and the
 #   traffic of the pivot kernels (profiles/pivot_loop_traffic.json is keyed by the hash of the kernel sources).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 E=$R/gpurun_out/ev
@@ -19,8 +19,10 @@ find $E/prof_c3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $E/c3_ker
 find $E/prof_b3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $E/batch_c3_kernel_stats.csv
 echo "kernel stats done"
 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 1536 C3 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c3.txt
+BLU_PIVOT_KERNEL=1 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 1536 C3 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c3_onewave.txt
 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 200 python tools/wave_phases.py 1024 C2 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c2_1024.txt
 bash tools/batch_pmc.sh C2 4096 k_pivot_loop_wave > $E/wave_sq_counters.txt 2>&1
+bash tools/batch_pmc.sh C3 1536 k_pivot_loop_wave2 > $E/wave2_sq_counters.txt 2>&1
 bash tools/pmc_calib.sh > $E/calib.log 2>&1
 bash tools/pmc_traffic.sh 1536 > $E/traffic.log 2>&1
 cp gpurun_out/pivot_loop_traffic.json gpurun_out/pmc_calib.json $E/ 2>/dev/null

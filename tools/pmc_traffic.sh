@@ -28,7 +28,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(R + "/gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            k = ("k_pivot_loop_wave" if "k_pivot_loop_wave" in kn else "k_pivot_loop_batch" if "k_pivot_loop_batch" in kn
+            k = ("k_pivot_loop_wave2" if "k_pivot_loop_wave2" in kn else "k_pivot_loop_wave" if "k_pivot_loop_wave" in kn else "k_pivot_loop_batch" if "k_pivot_loop_batch" in kn
                  else ("k_pivot_loop" if "k_pivot_loop" in kn else None))
             if k and r["Counter_Name"] == c:
                 vals[k][c].append(float(r["Counter_Value"]))
@@ -50,7 +50,7 @@ for k in tot:
     f = tot[k]["FETCH_SIZE"] / max(1, n[k]["FETCH_SIZE"]); w = tot[k]["WRITE_SIZE"] / max(1, n[k]["WRITE_SIZE"])
     rec["kernels"][k] = {"config": "C3", "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
                          "hbm_bytes_per_launch": 1024.0 * (f + w), "launches_seen": [n[k]["FETCH_SIZE"], n[k]["WRITE_SIZE"]]}
-    if k in ("k_pivot_loop_batch", "k_pivot_loop_wave"): rec["kernels"][k]["bases"] = BATCH
+    if k in ("k_pivot_loop_batch", "k_pivot_loop_wave", "k_pivot_loop_wave2"): rec["kernels"][k]["bases"] = BATCH
 # calibration of the counters on known-byte kernels (tools/pmc_calib.sh), when it was collected on this box
 try:
     rec["calibration"] = json.load(open(R + "/gpurun_out/pmc_calib.json"))

@@ -26,11 +26,16 @@ names = ["loop head", "search: heads / express / hand-over", "search: walk", "se
          "small: column finalize, U", "small: column hash, offsets", "small: rows pass", "small: row epilogue", "small: row append",
          "small: L column", "small: cleanup", "small: list move, walk of the next search begun", "scol: hash, offsets", "scol: pass", "scol: finalize, U",
          "scol: list move, hand-over, cleanup", "record pivot", "general paths"]
+if int(hs[0].stat(118)) == 3:  # k_pivot_loop_wave2 ran (a batch all of whose workgroups are resident): the clock of wave 0 (k_pivot_wave2.inc)
+    names[2] = "search: walk (begun while wave 1 updates the rows)"; names[6] = "small: publish to LDS, offsets"
+    names[10] = "small: column finalize"; names[14] = "small: the walk's first loads issued"
+    names[15] = "small: WAIT for wave 1 (the rows)"; names[16] = "small: U row, list move, L column, cleanup"
+    names[17] = "small: WAIT for wave 1 (its columns)"
 h = hs[0]
 tp = h.stat(K.STAT_DEV_TIME_PIVOT_LOOP)
 tot = sum(h.stat(60 + k) for k in range(24))
 npiv = h.stat(52) + h.stat(54)
-print("B=%d %s: pivot kernel %.3f s; basis 0: %.0f ticks in %d pivots (small %d, scol %d; searches handed over %d, with the walk begun early %d)" % (B, cfg, tp, tot, npiv, h.stat(54), h.stat(52), h.stat(116), h.stat(117)))
+print("B=%d %s (%s): pivot kernel %.3f s; basis 0: %.0f ticks in %d pivots (small %d, scol %d; searches handed over %d, with the walk begun early %d)" % (B, cfg, {0: "k_pivot_loop", 1: "k_pivot_loop_wave", 2: "k_pivot_loop_batch", 3: "k_pivot_loop_wave2"}[int(h.stat(118))], tp, tot, npiv, h.stat(54), h.stat(52), h.stat(116), h.stat(117)))
 for k, nm in enumerate(names):
     t, n = h.stat(60 + k), h.stat(84 + k)
     if n:
