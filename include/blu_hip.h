@@ -189,7 +189,8 @@ int blu_hip_update(blu_hip *h, double xtbl);
 /* Batch extension (no reference counterpart; the reference's only parallel
  * axis is independent BLU objects).  Factorizes n handles that
  * live on the same device concurrently: every kernel is launched once for the batch, the pivot loop with ONE WAVE
- * per handle (k_pivot_loop_wave; throughput grows with n up to 16 handles per CU, 4096 per MI355X).  Matrix k is
+ * per handle (k_pivot_loop_wave; throughput grows with n up to 16 handles per CU, 4096 per MI355X) -- with TWO waves
+ * per handle while n is at most half of that (k_pivot_loop_wave2: large bases, where HBM capacity limits n).  Matrix k is
  * given by the k-th pointers.  status[k] receives the per-handle status (also when the call as a whole
  * is refused: then every status[k] carries the refusal and no handle keeps usable factors).  The same
  * handle may not appear twice and all handles must live on one device (BLU_ERROR_INVALID_ARGUMENT).

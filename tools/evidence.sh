@@ -22,7 +22,7 @@ BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_ph
 BLU_PIVOT_KERNEL=1 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 1536 C3 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c3_onewave.txt
 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 200 python tools/wave_phases.py 1024 C2 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c2_1024.txt
 bash tools/batch_pmc.sh C2 4096 k_pivot_loop_wave > $E/wave_sq_counters.txt 2>&1
-bash tools/batch_pmc.sh C3 1536 k_pivot_loop_wave2 > $E/wave2_sq_counters.txt 2>&1
+bash tools/batch_pmc.sh C3 1536 k_pivot_loop_wave2 2 > $E/wave2_sq_counters.txt 2>&1
 bash tools/pmc_calib.sh > $E/calib.log 2>&1
 bash tools/pmc_traffic.sh 1536 > $E/traffic.log 2>&1
 cp gpurun_out/pivot_loop_traffic.json gpurun_out/pmc_calib.json $E/ 2>/dev/null
