@@ -122,6 +122,7 @@ struct blu_hip {
     GridWs *gw;        // scratch of the chip-wide O(nnz) phases (single-basis path)
     int grid_blocks;   // workgroups of their cooperative launches (0/1: one workgroup, as in a batch)
     int last_pivot_kernel;
+    int num_cus, batch_grid; // CUs of the device; workgroups of k_prep / k_setup / k_finish in a batch (0: one per CU; env BLU_BATCH_GRID)
     int wave2_max;     // bases the card holds at once with TWO waves each (k_pivot_loop_wave2): a batch up to this size takes that kernel
     std::string err;
     int64_t stop_at;   // debug: -1 off
@@ -343,6 +344,9 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         if (!prop.cooperativeLaunch) h->grid_blocks = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave2, 128, 0) != hipSuccess) nb = 0;
         h->wave2_max = nb * prop.multiProcessorCount;
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        const char *bg = getenv("BLU_BATCH_GRID");
+        h->batch_grid = bg ? atoi(bg) : 0;
         // the chain kernels keep ~106 KB of LDS rings per workgroup (k_chain.h)
         h->chain_ok = h->grid_blocks > 1 && (size_t)prop.sharedMemPerBlock >= sizeof(ChainLds) &&
                       hipFuncSetAttribute((const void *)k_stats_chains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainLds)) == hipSuccess &&

@@ -247,16 +247,19 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         S->u_nz = u_tot - m;
     }
 }
-__global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os)
+__global__ void __launch_bounds__(1024) k_finish(DevLU *Ds, FinishOut *Os, int nmat)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
     __shared__ double shd[40];
     __shared__ int lds_k[16 * WSORT_MAX];
     __shared__ double lds_v[16 * WSORT_MAX];
-    const DevG D(Ds[blockIdx.x]);
-    BlockScope sc{sh, shl};
-    finish_body(D, Os[blockIdx.x], sc, shd, lds_k, lds_v);
+    for (int b = blockIdx.x; b < nmat; b += gridDim.x) { // (see k_prep)
+        const DevG D(Ds[b]);
+        BlockScope sc{sh, shl};
+        finish_body(D, Os[b], sc, shd, lds_k, lds_v);
+        __syncthreads();
+    }
 }
 __global__ void __launch_bounds__(1024) k_finish_grid(DevLU *Ds, FinishOut *Os, GridWs *gw)
 {

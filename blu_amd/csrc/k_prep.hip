@@ -370,13 +370,18 @@ template <class Scope> __device__ __forceinline__ void prep_body(const DevG &D, 
         S->uused = uused;
     }
 }
-__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds)
+// One workgroup per matrix AT A TIME: the grid is smaller than a large batch and each workgroup takes matrices
+// blockIdx.x, + gridDim.x, ... (blu_driver.inc: batch_grid).
+__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds, int nmat)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
-    const DevG D(Ds[blockIdx.x]);
-    BlockScope sc{sh, shl};
-    prep_body(D, sc);
+    for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
+        const DevG D(Ds[b]);
+        BlockScope sc{sh, shl};
+        prep_body(D, sc);
+        __syncthreads();
+    }
 }
 __global__ void __launch_bounds__(1024) k_prep_grid(DevLU *Ds, GridWs *gw)
 {
@@ -538,13 +543,16 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         S->rankdef = 0;
     }
 }
-__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds)
+__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds, int nmat)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
-    const DevG D(Ds[blockIdx.x]);
-    BlockScope sc{sh, shl};
-    setup_body(D, sc);
+    for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
+        const DevG D(Ds[b]);
+        BlockScope sc{sh, shl};
+        setup_body(D, sc);
+        __syncthreads();
+    }
 }
 __global__ void __launch_bounds__(1024) k_setup_grid(DevLU *Ds, GridWs *gw)
 {
