@@ -55,7 +55,36 @@ __device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, 
 // ---------------------------------------------------------------------------------------------
 // k_prep
 // ---------------------------------------------------------------------------------------------
-template <class Scope> __device__ __forceinline__ void prep_body(const DevG &D, Scope &sc)
+// Sort of a short row (n <= N pairs, keys possibly equal: ties keep their order, so duplicates end up neighbours) by
+// one thread without a dependent chain of memory accesses: every pair into registers (the loads are issued together),
+// ranked there, stored where it belongs.  The insertion sort through memory costs ~n^2/4 dependent round trips.
+template <int N> __device__ __forceinline__ void reg_sort_row(gint_p idx, gdouble_p val, int b, int n)
+{
+    int k[N];
+    double v[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        k[i] = 0x7fffffff;
+        v[i] = 0.0;
+        if (i < n) {
+            k[i] = idx[b + i];
+            v[i] = val[b + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (i < n) {
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < N; j++) r += (k[j] < k[i] || (j < i && k[j] == k[i])) ? 1 : 0;
+            idx[b + r] = k[i];
+            val[b + r] = v[i];
+        }
+    }
+}
+
+// REGSORT: short rows by reg_sort_row (the 256-thread workgroups of a batch: their register budget allows it)
+template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(const DevG &D, Scope &sc)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -164,17 +193,23 @@ template <class Scope> __device__ __forceinline__ void prep_body(const DevG &D, 
             D.iw2[k] = i; // list of long rows (order irrelevant)
             continue;
         }
-        for (int p = b + 1; p < e; p++) {
-            const int kj = D.bt_idx[p];
-            const double kv = D.bt_val[p];
-            int q = p - 1;
-            while (q >= b && D.bt_idx[q] > kj) {
-                D.bt_idx[q + 1] = D.bt_idx[q];
-                D.bt_val[q + 1] = D.bt_val[q];
-                q--;
+        if (REGSORT && e - b <= 16) {
+            reg_sort_row<16>(D.bt_idx, D.bt_val, b, e - b);
+        } else if (REGSORT && e - b <= 32) {
+            reg_sort_row<32>(D.bt_idx, D.bt_val, b, e - b);
+        } else {
+            for (int p = b + 1; p < e; p++) {
+                const int kj = D.bt_idx[p];
+                const double kv = D.bt_val[p];
+                int q = p - 1;
+                while (q >= b && D.bt_idx[q] > kj) {
+                    D.bt_idx[q + 1] = D.bt_idx[q];
+                    D.bt_val[q + 1] = D.bt_val[q];
+                    q--;
+                }
+                D.bt_idx[q + 1] = kj;
+                D.bt_val[q + 1] = kv;
             }
-            D.bt_idx[q + 1] = kj;
-            D.bt_val[q + 1] = kv;
         }
         for (int p = b + 1; p < e; p++)
             if (D.bt_idx[p] == D.bt_idx[p - 1]) bad = 1; // duplicate (singletons.rs:195-197)
@@ -372,14 +407,15 @@ template <class Scope> __device__ __forceinline__ void prep_body(const DevG &D, 
 }
 // One workgroup per matrix AT A TIME: the grid is smaller than a large batch and each workgroup takes matrices
 // blockIdx.x, + gridDim.x, ... (blu_driver.inc: batch_grid).
-__global__ void __launch_bounds__(1024) k_prep(DevLU *Ds, int nmat)
+// NT = threads of the workgroup at most (256: a batch; 1024: one matrix without a cooperative launch)
+template <int NT> __global__ void __launch_bounds__(NT) k_prep(DevLU *Ds, int nmat)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        prep_body(D, sc);
+        prep_body<NT <= 256>(D, sc);
         __syncthreads();
     }
 }
@@ -389,7 +425,7 @@ __global__ void __launch_bounds__(1024) k_prep_grid(DevLU *Ds, GridWs *gw)
     __shared__ long long shl[20];
     const DevG D(Ds[0]);
     GridScope sc{sh, shl, gw, 0};
-    prep_body(D, sc);
+    prep_body<false>(D, sc);
 }
 
 // ---------------------------------------------------------------------------------------------
