@@ -240,6 +240,27 @@ __device__ __forceinline__ void wave_mem_sync(const char *f = __builtin_FILE(), 
 #else
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 #endif
+// A thread's walk over the entries [b, e) of a line, four entries per turn: load(p) -- everything entry p needs from
+// memory, dependent gathers included -- is called for four entries before use(p, what load gave) is for any, so their
+// round trips overlap.  Entry by entry such a walk is a chain of dependent round trips, and the O(nnz) kernels of a
+// batch run one workgroup per CU, which hides none of it.  use() is called in entry order.
+template <class Load, class Use> __device__ __forceinline__ void line4(int b, int e, Load load, Use use)
+{
+    int p = b;
+    for (; p + 4 <= e; p += 4) {
+        const auto a0 = load(p), a1 = load(p + 1), a2 = load(p + 2), a3 = load(p + 3);
+        use(p, a0);
+        use(p + 1, a1);
+        use(p + 2, a2);
+        use(p + 3, a3);
+    }
+    for (; p < e; p++) use(p, load(p));
+}
+struct IdxVal { // (what most such walks load per entry)
+    int i, g;   // the entry's index, something gathered through it
+    double v;
+};
+
 // A workgroup barrier that orders LDS only: the waves meet once each has its LDS operations behind it; its global
 // stores may still be in flight unless `drain` (a per-wave choice: only a wave whose stores another wave will load has
 // to wait for them).  __syncthreads() drains every wave's global stores, ~1-2 k cycles the waves mostly do not owe.

@@ -42,7 +42,7 @@ __device__ __forceinline__ void insertion_sort_pairs(long long *key, double *val
 // registers and stored where it belongs.  (The insertion sort above goes through memory for every comparison: ~n^2/4
 // dependent round trips per segment -- 0.14 of the 0.48 s of k_finish for 1536 bases of the 100k size.  Registers are
 // free here: these kernels run one workgroup per CU.)
-#define SSORT_MAX 24
+#define SSORT_MAX 32
 __device__ __forceinline__ void small_sort_pairs(long long *key, double *val, int b, int e)
 {
     const int n = e - b;
@@ -178,7 +178,24 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int ob = b + k;
         O.l_rowidx[ob] = k;
         O.l_value[ob] = 1.0;
-        for (int p = b; p < e; p++) {
+        // (four entries per turn: their loads -- index, then the gather through pinv -- are in flight together; a thread
+        // walking its line entry by entry is a chain of dependent round trips, and one workgroup per CU hides none)
+        int p = b;
+        for (; p + 4 <= e; p += 4) {
+            const int i0 = D.lidx[p], i1 = D.lidx[p + 1], i2 = D.lidx[p + 2], i3 = D.lidx[p + 3];
+            const double v0 = D.lval[p], v1 = D.lval[p + 1], v2 = D.lval[p + 2], v3 = D.lval[p + 3];
+            const int r0 = D.pinv[i0], r1 = D.pinv[i1], r2 = D.pinv[i2], r3 = D.pinv[i3];
+            const int o = ob + 1 + (p - b);
+            O.l_rowidx[o] = r0;
+            O.l_rowidx[o + 1] = r1;
+            O.l_rowidx[o + 2] = r2;
+            O.l_rowidx[o + 3] = r3;
+            O.l_value[o] = v0;
+            O.l_value[o + 1] = v1;
+            O.l_value[o + 2] = v2;
+            O.l_value[o + 3] = v3;
+        }
+        for (; p < e; p++) {
             O.l_rowidx[ob + 1 + (p - b)] = D.pinv[D.lidx[p]];
             O.l_value[ob + 1 + (p - b)] = D.lval[p];
         }
@@ -210,11 +227,22 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     // (build_factors.rs:318-337, `qinv[j] < rank`)
     for (int k = tid; k < m; k += nt) D.iw0[k] = 0;
     sc.sync();
-    for (int k = tid; k < rank; k += nt)
-        for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
+    for (int k = tid; k < rank; k += nt) {
+        const int e = D.ubeg[k + 1];
+        int p = D.ubeg[k];
+        for (; p + 4 <= e; p += 4) {
+            const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
+            const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
+            if (c0 < rank) g_atomic_add(&D.iw0[c0], 1);
+            if (c1 < rank) g_atomic_add(&D.iw0[c1], 1);
+            if (c2 < rank) g_atomic_add(&D.iw0[c2], 1);
+            if (c3 < rank) g_atomic_add(&D.iw0[c3], 1);
+        }
+        for (; p < e; p++) {
             const int c = D.qinv[D.uidx[p]];
             if (c < rank) g_atomic_add(&D.iw0[c], 1);
         }
+    }
     sc.sync();
     int base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
@@ -234,8 +262,35 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         *sc.ctr(0) = *sc.ctr(1) = 0;
     }
     sc.sync();
-    for (int k = tid; k < rank; k += nt)
-        for (int p = D.ubeg[k]; p < D.ubeg[k + 1]; p++) {
+    for (int k = tid; k < rank; k += nt) {
+        const int e = D.ubeg[k + 1];
+        int p = D.ubeg[k];
+        for (; p + 4 <= e; p += 4) { // (a column's entries are sorted afterwards: the order the cursors are taken in is free)
+            const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
+            const double v0 = D.uval[p], v1 = D.uval[p + 1], v2 = D.uval[p + 2], v3 = D.uval[p + 3];
+            const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
+            const int q0 = c0 < rank ? g_atomic_add(&D.iw1[c0], 1) : -1;
+            const int q1 = c1 < rank ? g_atomic_add(&D.iw1[c1], 1) : -1;
+            const int q2 = c2 < rank ? g_atomic_add(&D.iw1[c2], 1) : -1;
+            const int q3 = c3 < rank ? g_atomic_add(&D.iw1[c3], 1) : -1;
+            if (q0 >= 0) {
+                O.u_rowidx[q0] = k;
+                O.u_value[q0] = v0;
+            }
+            if (q1 >= 0) {
+                O.u_rowidx[q1] = k;
+                O.u_value[q1] = v1;
+            }
+            if (q2 >= 0) {
+                O.u_rowidx[q2] = k;
+                O.u_value[q2] = v2;
+            }
+            if (q3 >= 0) {
+                O.u_rowidx[q3] = k;
+                O.u_value[q3] = v3;
+            }
+        }
+        for (; p < e; p++) {
             const int c = D.qinv[D.uidx[p]];
             if (c < rank) {
                 const int pos = g_atomic_add(&D.iw1[c], 1);
@@ -243,6 +298,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
                 O.u_value[pos] = D.uval[p];
             }
         }
+    }
     sc.sync();
     double pmin = INFINITY, pmax = 0.0;
     for (int k = tid; k < m; k += nt) {

@@ -139,17 +139,26 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
     for (int j = tid; j < m; j += nt) {
         const unsigned long long b = D.b_begin[j], e = D.b_end[j];
         int put = D.bc_ptr[j];
-        for (unsigned long long pos = b; pos < e; pos++) {
-            const unsigned long long i = D.b_i[pos];
+        const auto take = [&](unsigned long long i, double x) {
             if (i >= (unsigned long long)m) {
                 bad = 1;
             } else {
                 g_atomic_add(&D.iw0[(int)i], 1);
                 D.bc_idx[put] = (int)i;
-                D.bc_val[put] = D.b_x[pos];
+                D.bc_val[put] = x;
             }
             put++;
+        };
+        unsigned long long pos = b;
+        for (; pos + 4 <= e; pos += 4) { // (four entries per turn, their loads in flight together: see line4, blu_dev.h)
+            const unsigned long long i0 = D.b_i[pos], i1 = D.b_i[pos + 1], i2 = D.b_i[pos + 2], i3 = D.b_i[pos + 3];
+            const double x0 = D.b_x[pos], x1 = D.b_x[pos + 1], x2 = D.b_x[pos + 2], x3 = D.b_x[pos + 3];
+            take(i0, x0);
+            take(i1, x1);
+            take(i2, x2);
+            take(i3, x3);
         }
+        for (; pos < e; pos++) take(D.b_i[pos], D.b_x[pos]);
     }
     bad = sc.any(bad); // (a grid barrier in the wide scope: the row counts of every workgroup are complete behind it)
     if (bad) {
@@ -175,14 +184,13 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
 
     // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
     // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
-    for (int j = tid; j < m; j += nt) {
-        for (int pos = D.bc_ptr[j]; pos < D.bc_ptr[j + 1]; pos++) {
-            const int i = D.bc_idx[pos];
-            const int p = g_atomic_add(&D.iw1[i], 1);
-            D.bt_idx[p] = j;
-            D.bt_val[p] = D.bc_val[pos];
-        }
-    }
+    for (int j = tid; j < m; j += nt)
+        line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
+              [&](int, const IdxVal &a) {
+                  const int p = g_atomic_add(&D.iw1[a.i], 1);
+                  D.bt_idx[p] = j;
+                  D.bt_val[p] = a.v;
+              });
     if (sc.leader()) *sc.ctr(0) = 0; // number of long rows
     sc.sync();
     // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the whole scope
@@ -450,11 +458,12 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         int cap = 0, cnz = 0, key = -2;
         double cmx = 0.0;
         if (j < m && D.qinv[j] < 0) {
-            for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
-                if (D.pinv[D.bc_idx[p]] >= 0) continue;
-                cmx = fmax(cmx, fabs(D.bc_val[p]));
-                cnz++;
-            }
+            line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, D.pinv[i], D.bc_val[p]}; },
+                  [&](int, const IdxVal &a) {
+                      if (a.g >= 0) return;
+                      cmx = fmax(cmx, fabs(a.v));
+                      cnz++;
+                  });
             if (cmx == 0.0 || cmx < abstol) {
                 key = 0;
                 dropped_nz += cnz;
@@ -489,13 +498,13 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     for (int j = tid; j < m; j += nt) {
         if (D.iw0[j] <= 0) continue;
         int put = D.cbeg[j];
-        for (int p = D.bc_ptr[j]; p < D.bc_ptr[j + 1]; p++) {
-            const int i = D.bc_idx[p];
-            if (D.pinv[i] >= 0) continue;
-            D.cidx[put] = i;
-            D.cval[put] = D.bc_val[p];
-            put++;
-        }
+        line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, D.pinv[i], D.bc_val[p]}; },
+              [&](int, const IdxVal &a) {
+                  if (a.g >= 0) return;
+                  D.cidx[put] = a.i;
+                  D.cval[put] = a.v;
+                  put++;
+              });
     }
 
     // ---- rows: pattern of the copied columns in ascending column order (setup_bump.rs:188-224)
@@ -504,7 +513,8 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         const int i = c0 + tid;
         int cap = 0, rnz = 0, key = -2;
         if (i < m && D.pinv[i] < 0) {
-            for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) rnz += (D.iw0[D.bt_idx[p]] > 0);
+            line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, D.iw0[j], 0.0}; },
+                  [&](int, const IdxVal &a) { rnz += (a.g > 0); });
             key = rnz;
             cap = rnz + stretch_of(stretch, rnz) + pad;
         }
@@ -530,10 +540,10 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     for (int i = tid; i < m; i += nt) {
         if (D.iw1[i] < 0) continue;
         int put = D.rbeg[i];
-        for (int p = D.bt_ptr[i]; p < D.bt_ptr[i + 1]; p++) {
-            const int j = D.bt_idx[p];
-            if (D.iw0[j] > 0) D.ridx[put++] = j;
-        }
+        line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, D.iw0[j], 0.0}; },
+              [&](int, const IdxVal &a) {
+                  if (a.g > 0) D.ridx[put++] = a.i;
+              });
     }
 
     // ---- count lists (setup_bump.rs:124-130, 188-194): list_init, then list_add in ascending index
