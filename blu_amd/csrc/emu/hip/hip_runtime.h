@@ -42,6 +42,8 @@ struct dim3 {
 };
 struct int2 { int x, y; };
 inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
+struct double2 { double x, y; };
+inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) int4 { int x, y, z, w; };
 
 namespace emu {

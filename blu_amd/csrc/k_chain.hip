@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_stats_tail_a(DevLU *Ds, FinishOut *Os,
     __shared__ double red[4][40];
     if (S->status != ST_DONE || D.skip_stats) return;
     double v[4];
-    stats_tail_loops(D, O, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x), v[0], v[1], v[2], v[3]);
+    stats_tail_loops<false>(D, O, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x), v[0], v[1], v[2], v[3]);
     for (int q = 0; q < 4; q++) {
         const double x = wave_max_d(v[q]);
         if (lane_id() == 0) red[q][wave_id()] = x;

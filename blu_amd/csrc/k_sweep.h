@@ -115,6 +115,25 @@ struct LStage {
         }
         return E;
     }
+    // the same in two halves, for a sweep that fetches them one step apart (sweep_dot_mapped): the row index as stored,
+    // then its position
+    __device__ __forceinline__ ColEnt ent_raw(const ColPtr &P) const
+    {
+        ColEnt E;
+        E.idx = 0;
+        E.val = 0.0;
+        const long long p = P.b + lane_id();
+        if (p < P.e) {
+            E.idx = lidx[p];
+            E.val = lval[p];
+        }
+        return E;
+    }
+    __device__ __forceinline__ ColEnt ent_map(const ColPtr &P, ColEnt E) const
+    {
+        if (P.b + lane_id() < P.e) E.idx = map[E.idx];
+        return E;
+    }
 };
 
 // sum of prod over lanes 0..n-1 in lane order, every lane gets it (the reference's sequential loop)
@@ -261,6 +280,65 @@ __device__ __forceinline__ void sweep_dot(const Cols &C, int k0, int dir, int n,
         Pb = Pc;
         Eb = Ec;
         Pc = Pd;
+    }
+}
+
+// sweep_dot over a column set whose entry indices go through a map (LStage with map: row index -> position).  The
+// entries of a step are then TWO dependent loads, and fetched two steps ahead as in sweep_dot the second load has to
+// wait for the first inside the step that issues both -- a whole round trip on the step-to-step chain (the backward
+// residual chain of a batch took 2x the time of the other three for it).  Here the pipeline is one stage deeper:
+// pointers four steps ahead, stored indices three, their positions two, the gather of x one.
+template <class Cols, class WIdx, class F>
+__device__ __forceinline__ void sweep_dot_mapped(const Cols &C, int k0, int dir, int n, gdouble_p x, WIdx widx, F f)
+{
+    if (n <= 0) return;
+    const int lane = lane_id();
+    ColPtr Pa = C.ptr(k0);
+    ColEnt Ea = C.ent(Pa, 0);
+    ColPtr Pb = C.ptr(k0 + dir);
+    ColEnt Eb = C.ent(Pb, 0);
+    ColPtr Pc = C.ptr(k0 + 2 * dir);
+    ColEnt Ecr = C.ent_raw(Pc);
+    ColPtr Pd = C.ptr(k0 + 3 * dir);
+    double Ga = (lane < Pa.e - Pa.b) ? x[Ea.idx] : 0.0;
+    double owna = x[widx(k0, Pa)];
+    for (int s = 0, k = k0; s < n; s++, k += dir) {
+        // ahead: gather and own value of step k+1, positions of k+2, stored indices of k+3, pointers of k+4
+        const int kb = k + dir;
+        const bool has_b = s + 1 < n;
+        const int wb = widx(kb, Pb);
+        double Gb = (has_b && lane < Pb.e - Pb.b) ? x[Eb.idx] : 0.0;
+        const double ownb = has_b ? x[wb] : 0.0;
+        const ColEnt Ec = C.ent_map(Pc, Ecr);
+        const ColEnt Edr = C.ent_raw(Pd);
+        const ColPtr Pe = C.ptr(k + 4 * dir);
+        // step k
+        const long long len = Pa.e - Pa.b;
+        double dot = 0.0;
+        if (len > 0) {
+            const int n0 = len < 64 ? (int)len : 64;
+            dot = wave_ordered_sum(lane < n0 ? __dmul_rn(Ga, Ea.val) : 0.0, n0, 0.0);
+            for (long long off = 64; off < len; off += 64) { // long column: the rest straight from memory
+                const ColEnt E2 = C.ent(Pa, off);
+                const int n2 = (len - off) < 64 ? (int)(len - off) : 64;
+                dot = wave_ordered_sum(lane < n2 ? __dmul_rn(x[E2.idx], E2.val) : 0.0, n2, dot);
+            }
+        }
+        bool store = true;
+        const double v = f(k, Pa, dot, owna, store);
+        const int wa = widx(k, Pa);
+        if (store && lane == 0) x[wa] = v;
+        if (store && Eb.idx == wa) Gb = v; // the one value the early gather could not have seen
+        wave_mem_sync();
+        Pa = Pb;
+        Ea = Eb;
+        Ga = Gb;
+        owna = ownb;
+        Pb = Pc;
+        Eb = Ec;
+        Pc = Pd;
+        Ecr = Edr;
+        Pd = Pe;
     }
 }
 
