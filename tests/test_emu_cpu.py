@@ -62,8 +62,8 @@ def emu_lib():
     return EMU
 
 
-def run_child(emu_lib, spec, kernel, no_fast=False):
-    env = dict(os.environ, BLU_HIP_LIB=emu_lib, BLU_PIVOT_KERNEL=str(kernel))
+def run_child(emu_lib, spec, kernel, no_fast=False, extra_env=None):
+    env = dict(os.environ, BLU_HIP_LIB=emu_lib, BLU_PIVOT_KERNEL=str(kernel), **(extra_env or {}))
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "spec": spec, "no_fast": no_fast}], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -95,6 +95,13 @@ def test_wave_kernel_batch_on_the_cpu(emu_lib):
     """the batch entry: three bases of different sizes, one wave each"""
     fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6)], kernel=0)
     assert fast > 300
+
+
+def test_batch_with_two_workgroups_on_the_cpu(emu_lib):
+    """k_prep / k_setup / k_finish as two workgroups that take the batch's matrices one after the other (BLU_BATCH_GRID)"""
+    fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6), (120, 6, 6, 0.5, 4, 0.3),
+                               (260, 7, 9, 0.3, 5, 0.5)], kernel=0, extra_env={"BLU_BATCH_GRID": "2"})
+    assert fast > 400
 
 
 def test_general_paths_on_the_cpu(emu_lib):

@@ -358,6 +358,30 @@ def test_batch_of_independent_bases(blu, oracle):
     assert hs[0].factorize(mats[0][0][:-1], mats[0][0][1:], mats[0][1], mats[0][2]) == K.OK
 
 
+def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch):
+    """The O(nnz) kernels of a batch (k_prep, k_setup, k_finish, k_stats_tail) run a fixed number of workgroups, each
+    taking matrix after matrix (one per CU: a large batch).  Here 3 workgroups for 8 bases of different sizes (the
+    grid is read when a handle is created), so every workgroup goes through several matrices with the same LDS:
+    factors, counters and all statistics of every member as the oracle has them."""
+    specs = [(300, 5, 4, 0.5, 1, 0.3), (1200, 8, 8, 0.5, 2, 0.3), (150, 4, 3, 0.5, 3, 0.3), (2000, 8, 8, 0.5, 4, 0.3),
+             (700, 6, 6, 1.0, 5, 0.2), (900, 7, 8, 0.5, 21, 0.4), (400, 6, 6, 0.0, 13, 0.5), (2500, 10, 9, 0.5, 1, 0.3)]
+    mats = [oracle.gen_lp_basis(*s) for s in specs]
+    monkeypatch.setenv("BLU_BATCH_GRID", "3")
+    hs = [blu.BLU(len(cp) - 1, len(ri)) for cp, ri, v in mats]
+    monkeypatch.delenv("BLU_BATCH_GRID")
+    for rep in range(2):
+        sts = blu.blu.factorize_batch(hs, mats=mats)
+        for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
+            o, so = util.oracle_factorize(oracle, cp, ri, v, allow_d3=True)
+            assert sts[k] == so == K.OK, (k, sts[k], so)
+            util.assert_same_factors(h.get_factors(), o.get_factors())
+            for c in util.COUNTERS:
+                assert int(h.stat(getattr(K, "STAT_" + c))) == int(o.stat(getattr(K, "STAT_" + c))), (k, c)
+            for c in FSTATS + ("RESIDUAL_TEST", "MIN_PIVOT", "MAX_PIVOT"):
+                assert h.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), (k, c)
+            assert int(h.stat(118)) == 3  # a batch this small: two waves per basis (k_pivot_loop_wave2)
+
+
 @pytest.mark.parametrize("spec", [(3000, 9, 10, 0.4, 17, 0.4), (2500, 10, 9, 0.5, 1, 0.3), (1800, 6, 30, 0.1, 9, 1.0)],
                          ids=["mixed", "c3-like", "wide-band"])
 def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):
