@@ -122,6 +122,7 @@ struct blu_hip {
     GridWs *gw;        // scratch of the chip-wide O(nnz) phases (single-basis path)
     int grid_blocks;   // workgroups of their cooperative launches (0/1: one workgroup, as in a batch)
     int last_pivot_kernel;
+    int lds_window, lds_window_mode; // bytes of dynamic LDS the batch forms of k_prep / k_finish may use as a counter window (0: not available), and when (env BLU_LDS_WINDOW)
     int num_cus, batch_grid; // CUs of the device; workgroups of k_prep / k_setup / k_finish in a batch (0: one per CU; env BLU_BATCH_GRID)
     int wave2_max;     // bases the card holds at once with TWO waves each (k_pivot_loop_wave2): a batch up to this size takes that kernel
     std::string err;
@@ -345,6 +346,22 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave2, 128, 0) != hipSuccess) nb = 0;
         h->wave2_max = nb * prop.multiProcessorCount;
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        {   // 144 KB of the CU's 160 KB as the counter window of k_prep / k_finish in a large batch.  Diagnostics:
+            // BLU_LDS_WINDOW = 0 never, 1 (default) a batch of at least one basis per CU, 2 every batch;
+            // BLU_LDS_WINDOW_BYTES = a smaller window (tests: several windows on small bases)
+            const char *lw = getenv("BLU_LDS_WINDOW"), *lb = getenv("BLU_LDS_WINDOW_BYTES");
+            h->lds_window_mode = lw ? atoi(lw) : 1;
+            const int want = 144 * 1024;
+            h->lds_window = 0;
+            if ((size_t)prop.sharedMemPerBlock >= (size_t)want + 4096 &&
+                hipFuncSetAttribute((const void *)k_prep<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_finish<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
+                h->lds_window = want;
+            if (lb && h->lds_window) {
+                const int v = atoi(lb) & ~15;
+                if (v >= 64 && v < want) h->lds_window = v;
+            }
+        }
         const char *bg = getenv("BLU_BATCH_GRID");
         h->batch_grid = bg ? atoi(bg) : 0;
         // the chain kernels keep ~106 KB of LDS rings per workgroup (k_chain.h)

@@ -275,7 +275,7 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
     snprintf(p->name, sizeof p->name, "CPU emulation (fibers)");
     snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:emu");
     p->totalGlobalMem = (size_t)8 << 30;
-    p->sharedMemPerBlock = 64 << 10;
+    p->sharedMemPerBlock = 160 << 10;
     p->multiProcessorCount = 1;
     p->cooperativeLaunch = 0;
     p->maxThreadsPerBlock = 1024;
@@ -306,7 +306,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = 1e-6 * (double)emu_memtime(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
-inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipErrorNotSupported; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 template <class F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 1; return hipSuccess; }
 inline hipError_t hipLaunchCooperativeKernel(const void *, dim3, dim3, void **, size_t, hipStream_t) { return hipErrorNotSupported; }
 #define hipLaunchKernelGGL(K, G, B, SH, ST, ...) emu::launch((G), (B), [=]() { K(__VA_ARGS__); })

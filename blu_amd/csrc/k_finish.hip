@@ -128,7 +128,8 @@ __device__ void scope_sort_segment(Scope &sc, long long *key, double *val, int b
 // REGSORT: short segments by small_sort_pairs (the 256-thread workgroups of a batch: their register budget allows it),
 // else by insertion_sort_pairs
 template <bool REGSORT, class Scope>
-__device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, Scope &sc, double *shd, int *lds_k, double *lds_v)
+__device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, Scope &sc, double *shd, int *lds_k, double *lds_v,
+                                            int *win = nullptr, int wincap = 0) // (win: an LDS window for the column counters, see prep_body)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -227,20 +228,37 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     // (build_factors.rs:318-337, `qinv[j] < rank`)
     for (int k = tid; k < m; k += nt) D.iw0[k] = 0;
     sc.sync();
-    for (int k = tid; k < rank; k += nt) {
-        const int e = D.ubeg[k + 1];
-        int p = D.ubeg[k];
-        for (; p + 4 <= e; p += 4) {
-            const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
-            const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
-            if (c0 < rank) g_atomic_add(&D.iw0[c0], 1);
-            if (c1 < rank) g_atomic_add(&D.iw0[c1], 1);
-            if (c2 < rank) g_atomic_add(&D.iw0[c2], 1);
-            if (c3 < rank) g_atomic_add(&D.iw0[c3], 1);
+    if (win) { // column counts through the LDS window
+        for (int w0 = 0; w0 < rank; w0 += wincap) {
+            const int wn = rank - w0 < wincap ? rank - w0 : wincap;
+            for (int i = tid; i < wn; i += nt) win[i] = 0;
+            sc.sync();
+            for (int k = tid; k < rank; k += nt)
+                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return D.qinv[D.uidx[p]]; },
+                      [&](int, int c) {
+                          const unsigned d = (unsigned)(c - w0);
+                          if (d < (unsigned)wn) atomicAdd(&win[d], 1);
+                      });
+            sc.sync();
+            for (int i = tid; i < wn; i += nt) D.iw0[w0 + i] = win[i];
+            sc.sync();
         }
-        for (; p < e; p++) {
-            const int c = D.qinv[D.uidx[p]];
-            if (c < rank) g_atomic_add(&D.iw0[c], 1);
+    } else {
+        for (int k = tid; k < rank; k += nt) {
+            const int e = D.ubeg[k + 1];
+            int p = D.ubeg[k];
+            for (; p + 4 <= e; p += 4) {
+                const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
+                const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
+                if (c0 < rank) g_atomic_add(&D.iw0[c0], 1);
+                if (c1 < rank) g_atomic_add(&D.iw0[c1], 1);
+                if (c2 < rank) g_atomic_add(&D.iw0[c2], 1);
+                if (c3 < rank) g_atomic_add(&D.iw0[c3], 1);
+            }
+            for (; p < e; p++) {
+                const int c = D.qinv[D.uidx[p]];
+                if (c < rank) g_atomic_add(&D.iw0[c], 1);
+            }
         }
     }
     sc.sync();
@@ -262,40 +280,59 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         *sc.ctr(0) = *sc.ctr(1) = 0;
     }
     sc.sync();
-    for (int k = tid; k < rank; k += nt) {
-        const int e = D.ubeg[k + 1];
-        int p = D.ubeg[k];
-        for (; p + 4 <= e; p += 4) { // (a column's entries are sorted afterwards: the order the cursors are taken in is free)
-            const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
-            const double v0 = D.uval[p], v1 = D.uval[p + 1], v2 = D.uval[p + 2], v3 = D.uval[p + 3];
-            const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
-            const int q0 = c0 < rank ? g_atomic_add(&D.iw1[c0], 1) : -1;
-            const int q1 = c1 < rank ? g_atomic_add(&D.iw1[c1], 1) : -1;
-            const int q2 = c2 < rank ? g_atomic_add(&D.iw1[c2], 1) : -1;
-            const int q3 = c3 < rank ? g_atomic_add(&D.iw1[c3], 1) : -1;
-            if (q0 >= 0) {
-                O.u_rowidx[q0] = k;
-                O.u_value[q0] = v0;
-            }
-            if (q1 >= 0) {
-                O.u_rowidx[q1] = k;
-                O.u_value[q1] = v1;
-            }
-            if (q2 >= 0) {
-                O.u_rowidx[q2] = k;
-                O.u_value[q2] = v2;
-            }
-            if (q3 >= 0) {
-                O.u_rowidx[q3] = k;
-                O.u_value[q3] = v3;
-            }
+    if (win) { // column cursors in the LDS window
+        for (int w0 = 0; w0 < rank; w0 += wincap) {
+            const int wn = rank - w0 < wincap ? rank - w0 : wincap;
+            for (int i = tid; i < wn; i += nt) win[i] = D.iw1[w0 + i];
+            sc.sync();
+            for (int k = tid; k < rank; k += nt)
+                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return IdxVal{0, D.qinv[D.uidx[p]], D.uval[p]}; },
+                      [&](int, const IdxVal &a) {
+                          const unsigned d = (unsigned)(a.g - w0);
+                          if (d < (unsigned)wn) {
+                              const int pos = atomicAdd(&win[d], 1);
+                              O.u_rowidx[pos] = k;
+                              O.u_value[pos] = a.v;
+                          }
+                      });
+            sc.sync();
         }
-        for (; p < e; p++) {
-            const int c = D.qinv[D.uidx[p]];
-            if (c < rank) {
-                const int pos = g_atomic_add(&D.iw1[c], 1);
-                O.u_rowidx[pos] = k;
-                O.u_value[pos] = D.uval[p];
+    } else {
+        for (int k = tid; k < rank; k += nt) {
+            const int e = D.ubeg[k + 1];
+            int p = D.ubeg[k];
+            for (; p + 4 <= e; p += 4) { // (a column's entries are sorted afterwards: the order the cursors are taken in is free)
+                const int j0 = D.uidx[p], j1 = D.uidx[p + 1], j2 = D.uidx[p + 2], j3 = D.uidx[p + 3];
+                const double v0 = D.uval[p], v1 = D.uval[p + 1], v2 = D.uval[p + 2], v3 = D.uval[p + 3];
+                const int c0 = D.qinv[j0], c1 = D.qinv[j1], c2 = D.qinv[j2], c3 = D.qinv[j3];
+                const int q0 = c0 < rank ? g_atomic_add(&D.iw1[c0], 1) : -1;
+                const int q1 = c1 < rank ? g_atomic_add(&D.iw1[c1], 1) : -1;
+                const int q2 = c2 < rank ? g_atomic_add(&D.iw1[c2], 1) : -1;
+                const int q3 = c3 < rank ? g_atomic_add(&D.iw1[c3], 1) : -1;
+                if (q0 >= 0) {
+                    O.u_rowidx[q0] = k;
+                    O.u_value[q0] = v0;
+                }
+                if (q1 >= 0) {
+                    O.u_rowidx[q1] = k;
+                    O.u_value[q1] = v1;
+                }
+                if (q2 >= 0) {
+                    O.u_rowidx[q2] = k;
+                    O.u_value[q2] = v2;
+                }
+                if (q3 >= 0) {
+                    O.u_rowidx[q3] = k;
+                    O.u_value[q3] = v3;
+                }
+            }
+            for (; p < e; p++) {
+                const int c = D.qinv[D.uidx[p]];
+                if (c < rank) {
+                    const int pos = g_atomic_add(&D.iw1[c], 1);
+                    O.u_rowidx[pos] = k;
+                    O.u_value[pos] = D.uval[p];
+                }
             }
         }
     }
@@ -340,8 +377,9 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     }
 }
 // NT = threads of the workgroup at most (256: a batch; 1024: one matrix without a cooperative launch)
-template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, FinishOut *Os, int nmat)
+template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, FinishOut *Os, int nmat, int winbytes)
 {
+    BLU_DYN_SHARED(unsigned char, finish_win, 144 * 1024); // (the counter window: winbytes of dynamic LDS, or none)
     __shared__ int sh[40];
     __shared__ long long shl[20];
     __shared__ double shd[40];
@@ -350,7 +388,7 @@ template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, Fini
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) { // (see k_prep)
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        finish_body<NT <= 256>(D, Os[b], sc, shd, lds_k, lds_v);
+        finish_body<NT <= 256>(D, Os[b], sc, shd, lds_k, lds_v, winbytes > 0 ? (int *)finish_win : nullptr, winbytes / 4);
         __syncthreads();
     }
 }

@@ -84,7 +84,12 @@ template <int N> __device__ __forceinline__ void reg_sort_row(gint_p idx, gdoubl
 }
 
 // REGSORT: short rows by reg_sort_row (the 256-thread workgroups of a batch: their register budget allows it)
-template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(const DevG &D, Scope &sc)
+// win / wincap: an LDS window of wincap ints, or null.  Global atomics are performed at the memory side on this part
+// (TCC_EA0_ATOMIC == TCC_ATOMIC, whatever their scope): one round trip to HBM per entry of the matrix for the row
+// counts and again for the fill cursors.  A workgroup that has a CU's LDS to itself (a batch: one workgroup per CU)
+// counts and fills through LDS atomics instead, one window of rows at a time (three windows for 100 000 rows), reading
+// the packed row indices once per window.
+template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(const DevG &D, Scope &sc, int *win = nullptr, int wincap = 0)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -143,7 +148,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
             if (i >= (unsigned long long)m) {
                 bad = 1;
             } else {
-                g_atomic_add(&D.iw0[(int)i], 1);
+                if (!win) g_atomic_add(&D.iw0[(int)i], 1);
                 D.bc_idx[put] = (int)i;
                 D.bc_val[put] = x;
             }
@@ -165,6 +170,22 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         if (sc.leader()) set_error(S, ST_INVALID_ARG, __LINE__);
         return;
     }
+    if (win) { // row counts through the LDS window
+        for (int r0 = 0; r0 < m; r0 += wincap) {
+            const int wn = m - r0 < wincap ? m - r0 : wincap;
+            for (int i = tid; i < wn; i += nt) win[i] = 0;
+            sc.sync();
+            for (int j = tid; j < m; j += nt)
+                line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return D.bc_idx[pos]; },
+                      [&](int, int i) {
+                          const unsigned d = (unsigned)(i - r0);
+                          if (d < (unsigned)wn) atomicAdd(&win[d], 1);
+                      });
+            sc.sync();
+            for (int i = tid; i < wn; i += nt) D.iw0[r0 + i] = win[i];
+            sc.sync();
+        }
+    }
 
     // ---- row pointers (singletons.rs:176-183)
     base = 0;
@@ -184,13 +205,32 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
 
     // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
     // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
-    for (int j = tid; j < m; j += nt)
-        line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
-              [&](int, const IdxVal &a) {
-                  const int p = g_atomic_add(&D.iw1[a.i], 1);
-                  D.bt_idx[p] = j;
-                  D.bt_val[p] = a.v;
-              });
+    if (win) { // fill cursors in the LDS window
+        for (int r0 = 0; r0 < m; r0 += wincap) {
+            const int wn = m - r0 < wincap ? m - r0 : wincap;
+            for (int i = tid; i < wn; i += nt) win[i] = D.iw1[r0 + i];
+            sc.sync();
+            for (int j = tid; j < m; j += nt)
+                line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
+                      [&](int, const IdxVal &a) {
+                          const unsigned d = (unsigned)(a.i - r0);
+                          if (d < (unsigned)wn) {
+                              const int p = atomicAdd(&win[d], 1);
+                              D.bt_idx[p] = j;
+                              D.bt_val[p] = a.v;
+                          }
+                      });
+            sc.sync();
+        }
+    } else {
+        for (int j = tid; j < m; j += nt)
+            line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
+                  [&](int, const IdxVal &a) {
+                      const int p = g_atomic_add(&D.iw1[a.i], 1);
+                      D.bt_idx[p] = j;
+                      D.bt_val[p] = a.v;
+                  });
+    }
     if (sc.leader()) *sc.ctr(0) = 0; // number of long rows
     sc.sync();
     // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the whole scope
@@ -416,14 +456,16 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
 // One workgroup per matrix AT A TIME: the grid is smaller than a large batch and each workgroup takes matrices
 // blockIdx.x, + gridDim.x, ... (blu_driver.inc: batch_grid).
 // NT = threads of the workgroup at most (256: a batch; 1024: one matrix without a cooperative launch)
-template <int NT> __global__ void __launch_bounds__(NT) k_prep(DevLU *Ds, int nmat)
+// winbytes = dynamic LDS of the launch (the window of prep_body), 0: none
+template <int NT> __global__ void __launch_bounds__(NT) k_prep(DevLU *Ds, int nmat, int winbytes)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
+    BLU_DYN_SHARED(unsigned char, prep_win, 144 * 1024);
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        prep_body<NT <= 256>(D, sc);
+        prep_body<NT <= 256>(D, sc, winbytes > 0 ? (int *)prep_win : nullptr, winbytes / 4);
         __syncthreads();
     }
 }

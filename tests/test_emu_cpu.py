@@ -98,9 +98,10 @@ def test_wave_kernel_batch_on_the_cpu(emu_lib):
 
 
 def test_batch_with_two_workgroups_on_the_cpu(emu_lib):
-    """k_prep / k_setup / k_finish as two workgroups that take the batch's matrices one after the other (BLU_BATCH_GRID)"""
+    """k_prep / k_setup / k_finish as two workgroups that take the batch's matrices one after the other (BLU_BATCH_GRID),
+    their row / column counters through LDS windows of 1 KB (BLU_LDS_WINDOW: the path of a large batch)"""
     fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6), (120, 6, 6, 0.5, 4, 0.3),
-                               (260, 7, 9, 0.3, 5, 0.5)], kernel=0, extra_env={"BLU_BATCH_GRID": "2"})
+                               (260, 7, 9, 0.3, 5, 0.5)], kernel=0, extra_env={"BLU_BATCH_GRID": "2", "BLU_LDS_WINDOW": "2", "BLU_LDS_WINDOW_BYTES": "1024"})
     assert fast > 400
 
 

@@ -361,14 +361,19 @@ def test_batch_of_independent_bases(blu, oracle):
 def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch):
     """The O(nnz) kernels of a batch (k_prep, k_setup, k_finish, k_stats_tail) run a fixed number of workgroups, each
     taking matrix after matrix (one per CU: a large batch).  Here 3 workgroups for 8 bases of different sizes (the
-    grid is read when a handle is created), so every workgroup goes through several matrices with the same LDS:
-    factors, counters and all statistics of every member as the oracle has them."""
+    grid is read when a handle is created), so every workgroup goes through several matrices with the same LDS; and the
+    row / column counters of k_prep / k_finish go through their LDS window (a large batch: 144 KB), forced here and cut
+    down to 2 KB so that every matrix takes several windows: factors, counters and all statistics of every member as the
+    oracle has them."""
     specs = [(300, 5, 4, 0.5, 1, 0.3), (1200, 8, 8, 0.5, 2, 0.3), (150, 4, 3, 0.5, 3, 0.3), (2000, 8, 8, 0.5, 4, 0.3),
              (700, 6, 6, 1.0, 5, 0.2), (900, 7, 8, 0.5, 21, 0.4), (400, 6, 6, 0.0, 13, 0.5), (2500, 10, 9, 0.5, 1, 0.3)]
     mats = [oracle.gen_lp_basis(*s) for s in specs]
     monkeypatch.setenv("BLU_BATCH_GRID", "3")
+    monkeypatch.setenv("BLU_LDS_WINDOW", "2")
+    monkeypatch.setenv("BLU_LDS_WINDOW_BYTES", "2048")
     hs = [blu.BLU(len(cp) - 1, len(ri)) for cp, ri, v in mats]
-    monkeypatch.delenv("BLU_BATCH_GRID")
+    for name in ("BLU_BATCH_GRID", "BLU_LDS_WINDOW", "BLU_LDS_WINDOW_BYTES"):
+        monkeypatch.delenv(name)
     for rep in range(2):
         sts = blu.blu.factorize_batch(hs, mats=mats)
         for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
