@@ -355,7 +355,8 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
             h->lds_window = 0;
             if ((size_t)prop.sharedMemPerBlock >= (size_t)want + 4096 &&
                 hipFuncSetAttribute((const void *)k_prep<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
-                hipFuncSetAttribute((const void *)k_finish<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
+                hipFuncSetAttribute((const void *)k_finish<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_setup, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
                 h->lds_window = want;
             if (lb && h->lds_window) {
                 const int v = atoi(lb) & ~15;

@@ -481,7 +481,12 @@ __global__ void __launch_bounds__(1024) k_prep_grid(DevLU *Ds, GridWs *gw)
 // ---------------------------------------------------------------------------------------------
 // k_setup = setup_bump (setup_bump.rs:55-264)
 // ---------------------------------------------------------------------------------------------
-template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D, Scope &sc)
+// win / wincap: an LDS window of wincap ints, or null.  The four passes over the entries of B ask of every entry
+// whether its row is pivotal already (columns) / whether its column is active (rows): a scattered 4-byte gather each,
+// 64 bytes of HBM traffic per entry where the entry itself is 12, and what bounds these passes in a batch (400 KB of
+// flags per matrix x 256 matrices in flight is far beyond the L2).  One BIT per line answers the question: with the
+// window the flags are a bitmap in LDS (12.5 KB for 100 000 lines), built by ballots from one coalesced read.
+template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D, Scope &sc, int *win = nullptr, int wincap = 0)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -490,6 +495,22 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     const int rank = S->rank;
     const double abstol = D.abstol, stretch = D.stretch;
     const int pad = D.pad;
+    const bool usebm = win != nullptr && (long long)wincap * 32 >= (long long)m + 64; // (uniform)
+    const auto build_bm = [&](auto pred) { // bit e of the window = pred(e), e < m
+        for (int b0 = sc.wid() * 64; b0 < m; b0 += sc.nw() * 64) {
+            const int e = b0 + lane_id();
+            const unsigned long long bits = __ballot(e < m && pred(e));
+            if (lane_id() == 0) {
+                win[b0 >> 5] = (int)(unsigned)bits;
+                win[(b0 >> 5) + 1] = (int)(unsigned)(bits >> 32);
+            }
+        }
+        sc.sync();
+    };
+    const auto bm = [&](int e) { return (int)(((unsigned)win[e >> 5] >> (e & 31)) & 1u); };
+    const auto row_g = [&](int i) { return usebm ? (bm(i) ? 0 : -1) : D.pinv[i]; }; // >= 0: row i is pivotal already
+    const auto col_g = [&](int j) { return usebm ? bm(j) : D.iw0[j]; };             // > 0: column j is active
+    if (usebm) build_bm([&](int e) { return D.pinv[e] >= 0; });
 
     // ---- columns: count, maximum, capacity (setup_bump.rs:131-186).  iw0[j] = list key:
     //      -2 column not active, 0 dropped (cmx == 0 or < abstol), else cnz
@@ -500,7 +521,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         int cap = 0, cnz = 0, key = -2;
         double cmx = 0.0;
         if (j < m && D.qinv[j] < 0) {
-            line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, D.pinv[i], D.bc_val[p]}; },
+            line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, row_g(i), D.bc_val[p]}; },
                   [&](int, const IdxVal &a) {
                       if (a.g >= 0) return;
                       cmx = fmax(cmx, fabs(a.v));
@@ -540,7 +561,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     for (int j = tid; j < m; j += nt) {
         if (D.iw0[j] <= 0) continue;
         int put = D.cbeg[j];
-        line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, D.pinv[i], D.bc_val[p]}; },
+        line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int p) { const int i = D.bc_idx[p]; return IdxVal{i, row_g(i), D.bc_val[p]}; },
               [&](int, const IdxVal &a) {
                   if (a.g >= 0) return;
                   D.cidx[put] = a.i;
@@ -550,12 +571,16 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     }
 
     // ---- rows: pattern of the copied columns in ascending column order (setup_bump.rs:188-224)
+    if (usebm) {
+        sc.sync(); // (the column passes are done with the rows' bitmap)
+        build_bm([&](int e) { return D.iw0[e] > 0; });
+    }
     base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
         const int i = c0 + tid;
         int cap = 0, rnz = 0, key = -2;
         if (i < m && D.pinv[i] < 0) {
-            line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, D.iw0[j], 0.0}; },
+            line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, col_g(j), 0.0}; },
                   [&](int, const IdxVal &a) { rnz += (a.g > 0); });
             key = rnz;
             cap = rnz + stretch_of(stretch, rnz) + pad;
@@ -582,7 +607,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     for (int i = tid; i < m; i += nt) {
         if (D.iw1[i] < 0) continue;
         int put = D.rbeg[i];
-        line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, D.iw0[j], 0.0}; },
+        line4(D.bt_ptr[i], D.bt_ptr[i + 1], [&](int p) { const int j = D.bt_idx[p]; return IdxVal{j, col_g(j), 0.0}; },
               [&](int, const IdxVal &a) {
                   if (a.g > 0) D.ridx[put++] = a.i;
               });
@@ -631,14 +656,15 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         S->rankdef = 0;
     }
 }
-__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds, int nmat)
+__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds, int nmat, int winbytes)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
+    BLU_DYN_SHARED(unsigned char, setup_win, 144 * 1024); // (the flag bitmaps: winbytes of dynamic LDS, or none)
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        setup_body(D, sc);
+        setup_body(D, sc, winbytes > 0 ? (int *)setup_win : nullptr, winbytes / 4);
         __syncthreads();
     }
 }
