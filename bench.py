@@ -43,6 +43,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-sizes", action="store_true", help="skip the batched measurement on C4- and C2-size bases")
     ap.add_argument("--batch", type=int, default=1536, help="bases in flight for the secondary throughput measurement (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of the batched legs")
     ap.add_argument("--batch-block", type=int, default=256, help="workgroup size of the multi-wave pivot kernel in batch mode (BLU_PIVOT_KERNEL=2 only)")
     return ap.parse_args(argv)
 
@@ -81,29 +82,79 @@ def cpu_baseline(cp, ri, v, label, budget_s=12.0, max_reps=12):
             "seconds_per_factorize": med}
 
 
+def _verify_members(hs, member_seed, c, be, which):
+    """UNTIMED check of a batch as it was timed: members `which` against the CPU oracle (checker only; the faithful
+    restatement, reference defect D3 included, so d3_hits must be 0 on both sides): the six integer arrays of get_factors
+    and the values bit for bit, the counters, the pivots per pivot routine, every statistic of the tail."""
+    import numpy as np
+    from blu_amd import keys as K
+    from oracle import orc  # checker only, outside every timed region
+    orc.build()
+    cache = {}
+    for k in which:
+        seed = member_seed(k)
+        if seed not in cache:
+            cp, ri, v = be.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], seed, c["offscale"])
+            o = orc.OracleBLU(c["m"], 16 * len(ri))
+            if o.factorize(cp[:-1], cp[1:], ri, v) != K.OK or o.d3_hits() != 0:
+                raise RuntimeError("oracle run of seed %d failed" % seed)
+            cache[seed] = (o, o.get_factors())
+        o, fo = cache[seed]
+        h = hs[k]
+        fg = h.get_factors()
+        for key in ("rowperm", "colperm", "l_colptr", "l_rowidx", "u_colptr", "u_rowidx", "l_value", "u_value"):
+            if not np.array_equal(fg[key], fo[key]):
+                raise RuntimeError("batched factorize: member %d (seed %d) differs from the oracle in %s" % (k, seed, key))
+        keys = [K.STAT_RANK, K.STAT_MATRIX_NZ, K.STAT_BUMP_SIZE, K.STAT_BUMP_NZ, K.STAT_L_NZ, K.STAT_U_NZ, K.STAT_NSEARCH_PIVOT,
+                K.STAT_FACTOR_FLOPS, K.STAT_RANKDEF, 50, 51, 52, 53, 54, 55, 56, K.STAT_MIN_PIVOT, K.STAT_MAX_PIVOT, K.STAT_CONDEST_L,
+                K.STAT_CONDEST_U, K.STAT_NORM_L, K.STAT_NORM_U, K.STAT_NORMEST_L_INV, K.STAT_NORMEST_U_INV, K.STAT_ONENORM,
+                K.STAT_INFNORM, K.STAT_RESIDUAL_TEST]
+        for key in keys:
+            if h.stat(key) != o.stat(key):
+                raise RuntimeError("batched factorize: member %d (seed %d) differs from the oracle in statistic %d" % (k, seed, key))
+    return len(which)
+
+
+def batch_setup(c, B, dev, local_rank, be, hintdiv=2, nd=64):
+    """B handles of configuration c over min(B, nd) distinct matrices (seeds 1000 + k mod nd), every handle with device
+    copies of its inputs of its own.  Returns (handles, device pointers, the tensors that own the inputs, seed of member k,
+    number of distinct matrices, total nnz).  Also used by tools/batch_probe.py, so that probes and PMC passes run what
+    bench.py times."""
+    import numpy as np
+    import torch
+    nd = min(B, nd)
+
+    def member_seed(k):
+        return 1000 + k % nd
+
+    mats = [be.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], member_seed(s), c["offscale"]) for s in range(nd)]
+    inputs, ptrs = [], []
+    for k in range(B):
+        cp, ri, v = mats[k % nd]
+        t = (torch.from_numpy(cp.view(np.int64)).to(dev), torch.from_numpy(ri.view(np.int64)).to(dev), torch.from_numpy(v).to(dev))
+        inputs.append(t)  # (kept alive: the handles borrow them for every call)
+        ptrs.append((t[0].data_ptr(), t[0].data_ptr() + 8, t[1].data_ptr(), t[2].data_ptr(), len(ri)))
+    hs = [be.BLU(c["m"], len(mats[k % nd][1]) // hintdiv, device=local_rank) for k in range(B)]
+    return hs, ptrs, inputs, member_seed, nd, sum(p[4] for p in ptrs)
+
+
 def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=None):
     """SECONDARY measurement (never `value`): B independent bases of the same configuration in flight
     on this GPU (blu_hip_factorize_batch): one wave per basis in the pivot kernel (k_pivot_loop_wave), two while the card
     holds no more than half the bases its registers would allow (k_pivot_loop_wave2: bases of the 100k size).  A
     single factorize is a chain of dependent pivots and can not use more than one CU; this is the mode in
-    which the chip fills up.  8 distinct matrices (seeds) are cycled over the B handles; inputs resident in HBM."""
+    which the chip fills up.  64 distinct matrices (seeds 1000..1063) over the B handles, EVERY handle with device
+    inputs of its own (no two workgroups read the same copy of B); the first step (cold: storage growth, compaction
+    rounds, relaunches) is reported on its own, then the MEDIAN of three warm steps; after the timed steps, untimed,
+    eight members (first, last, six in between) are checked against the CPU oracle (`verified_members`)."""
     import numpy as np
     import torch
     from blu_amd import keys as K, shard
     B = args.batch if B is None else B
     cfg_name = args.config if cfg_name is None else cfg_name
-    nd = min(B, 8)
-    mats = []
-    for s in range(nd):
-        cp, ri, v = be.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], 1000 + s, c["offscale"])
-        mats.append((torch.from_numpy(cp.view(np.int64)).to(dev), torch.from_numpy(ri.view(np.int64)).to(dev),
-                     torch.from_numpy(v).to(dev), len(ri)))
-    hs = [be.BLU(c["m"], mats[k % nd][3] // 2, device=local_rank) for k in range(B)]
-    ptrs = [(mats[k % nd][0].data_ptr(), mats[k % nd][0].data_ptr() + 8, mats[k % nd][1].data_ptr(),
-             mats[k % nd][2].data_ptr(), mats[k % nd][3]) for k in range(B)]
-    nnz = sum(p[4] for p in ptrs)
-    best = None
-    for rep in range(3):  # rep 0 warms up (storage growth), best of the other two
+    hs, ptrs, inputs, member_seed, nd, nnz = batch_setup(c, B, dev, local_rank, be)
+    runs = []
+    for rep in range(4):  # rep 0 is the cold step, reported on its own; the median of the other three is the result
         shard.fence(dev)
         t0 = time.perf_counter()
         st = be.factorize_batch(hs, device_ptrs=ptrs, block=args.batch_block)
@@ -111,28 +162,42 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
         el = time.perf_counter() - t0
         if any(s != K.OK for s in st):
             raise RuntimeError("batched factorize failed: %r" % (st,))
-        if rep > 0 and (best is None or el < best[0]):
-            F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs)
-            lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
-            which = int(hs[0].stat(118))  # the pivot kernel the library chose (blu_driver.inc: batch_pivot_and_finish)
-            best = (el, hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP), int(hs[0].stat(K.STAT_DEV_RELAUNCHES)), F, lu,
-                    [hs[0].stat(k) for k in (44, 45, 46, 47)],
-                    (hs[0].stat(110) + hs[0].stat(111)) / max(1.0, hs[0].stat(52) + hs[0].stat(54)))
-    el = shard.max_over_ranks(best[0], dev)
-    t_piv, nl, F, lu, hs_phase, fast_share = best[1], best[2], best[3], best[4], best[5], best[6]
+        runs.append((el, hs[0].stat(K.STAT_DEV_TIME_PIVOT_LOOP), int(hs[0].stat(K.STAT_DEV_RELAUNCHES)),
+                     [hs[0].stat(k) for k in (44, 45, 46, 47)]))
+    cold = runs[0]
+    warm = sorted(runs[1:], key=lambda r: r[0])
+    med = warm[len(warm) // 2]
+    F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs)
+    lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
+    which = int(hs[0].stat(118))  # the pivot kernel the library chose (blu_driver.inc: batch_pivot_and_finish)
+    fast_share = (sum(h.stat(110) + h.stat(111) for h in hs[:64])) / max(1.0, sum(h.stat(52) + h.stat(54) for h in hs[:64]))
+    el = shard.max_over_ranks(med[0], dev)
+    t_piv, nl, hs_phase = med[1], med[2], med[3]
     gbs = (32.0 * F + 32.0 * lu) / t_piv / 1e9
+    sample = sorted(set([0, B - 1] + [(q * B) // 7 for q in range(1, 7)]))
+    verified = _verify_members(hs, member_seed, c, be, sample) if not args.no_verify else 0
     for h in hs:
         h.close()
+    del inputs, ptrs
+    torch.cuda.empty_cache()  # (the next leg needs the card: torch would keep the freed inputs cached)
     traffic = None
     kname = {0: "k_pivot_loop", 1: "k_pivot_loop_wave", 2: "k_pivot_loop_batch", 3: "k_pivot_loop_wave2"}[which]
     wg_threads = {0: args.batch_block, 1: 64, 2: args.batch_block, 3: 128}[which]
-    tinfo = _traffic_record(kname)
+    tinfo = _traffic_record("%s@%s" % (kname, cfg_name)) or _traffic_record(kname)
     if tinfo and tinfo.get("bases") == B and tinfo.get("config") == cfg_name:
         traffic = tinfo["hbm_bytes_per_launch"] / max(t_piv / max(nl, 1), 1e-12) / 1e9
-    return {"config": "%s-size bases (m = %d)" % (cfg_name, c["m"]), "bases_in_flight_per_gpu": B, "workgroup_threads": wg_threads, "nnz_per_s": world * nnz / el,
-            "seconds": el, "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
+    return {"config": "%s-size bases (m = %d; lp_basis k=%d bw=%d tri_frac=%g offscale=%g, seeds 1000..%d)" % (
+                cfg_name, c["m"], c["k"], c["bw"], c["tri_frac"], c["offscale"], 999 + nd),
+            "bases_in_flight_per_gpu": B, "distinct_matrices": nd, "inputs": "one device copy of B per handle",
+            "workgroup_threads": wg_threads, "nnz_per_s": world * nnz / el,
+            "seconds": el, "seconds_warm_steps": [r[0] for r in runs[1:]], "timing": "median of 3 warm steps",
+            "cold_first_step": {"seconds": cold[0], "pivot_kernel_seconds": cold[1], "pivot_kernel_launches": cold[2],
+                                "note": "handles created with hint nnz/2: storage growth, compaction rounds and relaunches included"},
+            "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
             "phases_seconds": {"k_prep": hs_phase[0], "k_setup": hs_phase[1], "k_finish": hs_phase[2], "k_stats": hs_phase[3]},
-            "flattened_path_share": fast_share,
+            "flattened_path_share": fast_share, "verified_members": verified,
+            "verified_against": "CPU oracle, untimed, after the timed steps: members %s -- integer arrays, values, counters, "
+                                "pivots per routine, statistics bit-identical" % (sample,),
             "roofline": {"bound": "hbm", "kernel": "%s (grid = %d workgroups)" % (kname, B), "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic},
             "note": "throughput mode, reported beside the headline; `value` above is ONE basis per GPU"}
@@ -334,7 +399,10 @@ def rank_main(args, backend=None, device=None):
                                                                   CONFIGS[args.config]["seed"], nnz),
                    "m": m, "nnz": nnz, "l_nz": l_nz, "u_nz": u_nz, "factor_flops": F,
                    "rank": h.stat(K.STAT_RANK), "bump_size": h.stat(K.STAT_BUMP_SIZE),
-                   "nsearch_pivot": h.stat(K.STAT_NSEARCH_PIVOT), "parallelism": "one basis per GPU, no data-path collective"},
+                   "nsearch_pivot": h.stat(K.STAT_NSEARCH_PIVOT), "parallelism": "one basis per GPU, no data-path collective",
+                   "generator_note": "bw = %d, not SURVEY.md 8d's provisional 16: at bw = 16 the reference's i32 cancellation mask (defect D3, "
+                                     "pivot.rs:645-659) is hit and the reference has no defined result; bw = %d keeps d3_hits == 0 (fill %.1fx "
+                                     "nnz(B)); BASELINE.md section 8" % (c["bw"], c["bw"], (l_nz + u_nz) / max(1, nnz))},
         "roofline": {"bound": "hbm", "kernel": "k_pivot_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": ("profiles/pivot_loop_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch / avg launch time, GB/s)"

@@ -84,8 +84,8 @@ struct blu_hip {
     double *ob_x;
     int64_t ob_mcap, ob_nzcap;
     // solve workspace
-    double *d_rhs, *d_lhs;
-    int *lvl_l, *lvl_u;
+    double *d_rhs, *d_lhs; // solve_dense right-hand side / solution on the device (allocated at the first solve_dense)
+    int gwork_cols;        // columns of m + 1 doubles D.gwork holds: 9 (statistics) or the waves of the pivot kernel, whichever is more
     // solve_sparse workspace (allocated at the first call)
     SparseWs sw;
     bool sw_ready;
@@ -180,6 +180,7 @@ static void free_all(blu_hip *h)
     dfree(W.marked); dfree(W.psym); dfree(W.pat); dfree(W.pstack); dfree(W.estack); dfree(W.work); dfree(W.xlhs); dfree(W.ilhs);
     dfree(W.xval); dfree(W.out); dfree(W.lt_ptr); dfree(W.lt_idx); dfree(W.lt_val); dfree(W.lt_cur);
     dfree(h->d_irhs); dfree(h->d_xrhs);
+    dfree(h->d_rhs); dfree(h->d_lhs); dfree(D.gwork);
     dfree(h->ur_len); dfree(h->ur_pos); dfree(h->ur_val);
     free_upd(h);
     // everything else lives in the slab
@@ -307,19 +308,23 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     want(&D.cflink, 2 * M + 2); want(&D.cblink, 2 * M + 2); want(&D.rflink, 2 * M + 2); want(&D.rblink, 2 * M + 2);
     want(&D.rowmark, M); want(&D.colmark, M);
     want(&D.tnew, M + 2); want(&D.tnewr, M + 2); want(&D.txrj, M + 2); want(&D.tmask, M + 2);
-    want(&D.gwork, 16 * (M + 1));
     want(&D.iw0, M + 2); want(&D.iw1, M + 2); want(&D.iw2, M + 2);
     want(&D.lbeg, M + 1); want(&D.ubeg, M + 1);
     want(&D.s, 1); want(&h->dD, 1); want(&h->dO, 1); want(&h->gw, 1);
     want(&h->O.rowperm, M); want(&h->O.colperm, M); want(&h->O.l_colptr, M + 1); want(&h->O.u_colptr, M + 1);
-    want(&h->d_rhs, M); want(&h->d_lhs, M); want(&h->lvl_l, M + 2); want(&h->lvl_u, M + 2);
     ok = ok && dalloc(h, &h->slab, slab_bytes);
     if (ok)
         for (auto &r : reqs) *r.first = (void *)(h->slab + r.second);
     ok = ok && dalloc(h, &D.bc_idx, D.nzcap) && dalloc(h, &D.bc_val, D.nzcap) && dalloc(h, &D.bt_idx, D.nzcap) && dalloc(h, &D.bt_val, D.nzcap);
     ok = ok && dalloc(h, &D.cidx, D.carena_cap) && dalloc(h, &D.cval, D.carena_cap) && dalloc(h, &D.ridx, D.rarena_cap);
     ok = ok && dalloc(h, &D.lidx, D.lcap) && dalloc(h, &D.lval, D.lcap) && dalloc(h, &D.uidx, D.ucap) && dalloc(h, &D.uval, D.ucap);
-    if (ok) ok = hip_ok(h, hipMemset(D.gwork, 0, 16 * (M + 1) * sizeof(double)), "hipMemset");
+    // gwork: the statistics use 8 columns of m + 1 doubles and two words more, pivot_any one dense work column per wave of
+    // the pivot kernel (16 for a single basis, 1 or 2 in a batch: ensure_gwork grows it before such a launch).  A batch is
+    // limited by HBM capacity: 9 columns instead of 16 are 5.6 MB less per handle of the 100k size.
+    h->gwork_cols = 9;
+    ok = ok && dalloc(h, &D.gwork, (size_t)h->gwork_cols * (M + 1));
+    if (ok) ok = hip_ok(h, hipMemset(D.gwork, 0, (size_t)h->gwork_cols * (M + 1) * sizeof(double)), "hipMemset");
+    h->d_rhs = h->d_lhs = nullptr;
     h->dslot = h->dD;
     h->oslot = h->dO;
     h->batch_block = 256;
@@ -547,6 +552,18 @@ extern "C" int blu_hip_device_count(void)
 // ---------------------------------------------------------------------------------------------
 // memory growth (the device-side counterpart of lu_realloc_obj, blu.rs:345-377)
 // ---------------------------------------------------------------------------------------------
+// gwork holds `cols` all-zero columns of m + 1 doubles (the state its users expect and restore)
+static bool ensure_gwork(blu_hip *h, int cols)
+{
+    if (cols <= h->gwork_cols) return true;
+    DevLU &D = h->D;
+    const size_t n = (size_t)cols * ((size_t)h->m + 1);
+    dfree(D.gwork);
+    h->gwork_cols = 0;
+    if (!dalloc(h, &D.gwork, n) || !hip_ok(h, hipMemset(D.gwork, 0, n * sizeof(double)), "hipMemset")) return false;
+    h->gwork_cols = cols;
+    return true;
+}
 static int64_t grown(blu_hip *h, int64_t cap, int64_t need_extra)
 {
     const double f = std::max(1.0, h->realloc_factor);
@@ -836,6 +853,7 @@ extern "C" int blu_hip_solve_dense(blu_hip *h, const double *rhs, double *lhs, c
     if (h->m == 0) return BLU_OK;
     if (hipSetDevice(h->device) != hipSuccess) return BLU_ERROR_DEVICE;
     const size_t M = (size_t)h->m;
+    if (!h->d_rhs && (!dalloc(h, &h->d_rhs, M) || !dalloc(h, &h->d_lhs, M))) return BLU_ERROR_OUT_OF_MEMORY;
     if (!hip_ok(h, hipMemcpy(h->d_rhs, rhs, M * 8, hipMemcpyHostToDevice), "h2d rhs")) return BLU_ERROR_DEVICE;
     const int tr = (trans == 't' || trans == 'T') ? 1 : 0;
     if (h->nupdate > 0) { // updated factorization: mutable U, row etas, pivot sequence (k_update.hip)

@@ -161,6 +161,17 @@ def test_batch_fuzz_slice(start):
     assert ("all 15 batches of seed 2025 from %d identical" % start) in text
 
 
+def test_batch_fuzz_slice_one_wave_kernel_forced():
+    """The same kind of random batches with k_pivot_loop_wave forced (BLU_PIVOT_KERNEL=1, read when a handle is created):
+    batches of 3..24 members take the two-wave kernel by default, the one-wave kernel is the default only beyond 2048."""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    log = os.path.join(out, "fuzzbatch_wave_s2026.log")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_batch_gpu.py"), "--seed", "2026", "--start", "0", "--count", "12", "--log", log]
+    text = _run_slice(cmd, log, "one-wave batch slice", env=dict(os.environ, BLU_PIVOT_KERNEL="1"))
+    assert "all 12 batches of seed 2026 from 0 identical" in text and "pivot kernels [1]" in text
+
+
 @pytest.mark.parametrize("args,tag", [(["--seed", "9090", "--start", "0", "--count", "150"], "all 150 cases of seed 9090 from 0 identical"),
                                       (["--seed", "33", "--start", "0", "--count", "15", "--mmin", "1500", "--mmax", "9000"],
                                        "all 15 cases of seed 33 from 0 identical")], ids=["small", "mid"])

@@ -154,6 +154,32 @@ def test_bench_rank_function_two_ranks_gloo():
     assert line["roofline"]["traffic"] is None or line["roofline"]["traffic"] > 0
 
 
+def test_bench_rank_function_eight_ranks_gloo_config_c4():
+    """The 8-rank dealing of C4 (shard.bases_of_rank(8, r, 8): one 50k basis per rank, seeds 1..8) through bench.rank_main, once,
+    before an 8-GPU node ever sees it: eight gloo ranks on the CPU (small stand-in bases), every rank its own seed, the
+    whole-job value = nnz of all eight bases x steps / max-over-ranks time, one JSON line from rank 0."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, seeds, res = q.get(timeout=300)
+        got[r] = (seeds, res)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [got[r][0] for r in range(world)] == [[1 + r] for r in range(world)]  # basis b -> rank b: seeds 1..8, no two alike
+    assert all(got[r][1] is None for r in range(1, world))
+    line = got[0][1]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["workload"].startswith("C4")
+    per_step = line["ms_per_step"] * 1e-3
+    assert line["value"] > line["config"]["nnz"] / per_step * 6.0  # eight bases' nnz over the slowest rank's time
+
+
 def test_bench_refuses_world_size_mismatch():
     import subprocess
     import sys

@@ -1,8 +1,13 @@
-"""Randomized parity run of the BATCH entry (blu_hip_factorize_batch -> k_pivot_loop_wave, one wave per basis):
-random batches of 3..24 small bases of mixed sizes with random generator parameters, per-handle LU parameters,
-capacity hints (small ones force device-side storage growth and relaunches) and numerically null columns; every
-member must equal its own oracle run -- status, canonical factors, counters, pivots per pivot routine, d3 events,
-statistics -- bit for bit.
+"""Randomized parity run of the BATCH entry (blu_hip_factorize_batch): random batches of 3..24 small bases of mixed
+sizes with random generator parameters, per-handle LU parameters, capacity hints (small ones force device-side storage
+growth and relaunches) and numerically null columns; every member must equal its own oracle run -- status, canonical
+factors, counters, pivots per pivot routine, d3 events, statistics -- bit for bit.
+
+Which pivot kernel runs: batches this small are resident with two waves per basis, so the library's default dispatch
+takes k_pivot_loop_wave2 (statistic 118 == 3).  The one-wave kernel k_pivot_loop_wave -- the default beyond 2048
+members -- is put under the same batches with BLU_PIVOT_KERNEL=1 in the environment (read when a handle is created;
+tests/test_gpu_fuzz.py::test_batch_fuzz_slice_one_wave_kernel_forced), and in the shape bench.py times it by
+tests/test_gpu_batch_as_benched.py.  The kernel that ran is printed with the result line.
 
    python tools/fuzz_batch_gpu.py [--seed S] [--start A] [--count N] [--log FILE]      (needs a GPU; the oracle is the checker)
 
@@ -31,6 +36,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     blu_amd = None
     members, fast, kinds = 0, 0, [0] * 6
+    ran = set()
     for batch in range(a.start + a.count):
         n = int(rng.integers(3, 25))
         cases = []
@@ -70,12 +76,13 @@ def main():
                     assert g.stat(51 + kind) == o.stat(51 + kind), (tag, "pivot kind", kind)
                     kinds[kind] += int(o.stat(51 + kind))
                 fast += int(g.stat(110)) + int(g.stat(111))
+                ran.add(int(g.stat(118)))
             members += 1
         for g in hs:
             g.close()
         log.write("done %d\n" % batch)
-    msg = "all %d batches of seed %d from %d identical (%d members; pivots by path %s, %d of them on the flattened paths)" % (
-        a.count, a.seed, a.start, members, kinds, fast)
+    msg = "all %d batches of seed %d from %d identical (%d members; pivots by path %s, %d of them on the flattened paths; pivot kernels %s)" % (
+        a.count, a.seed, a.start, members, kinds, fast, sorted(ran))
     log.write(msg + "\n")
     log.flush()
     if log is not sys.stdout:
