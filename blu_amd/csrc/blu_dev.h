@@ -101,8 +101,15 @@ struct Scalars {
 //   b_*            input matrix as handed over by the caller (device copies of the uint64 arrays)
 //   bc_*, bt_*     packed B: columnwise and rowwise-sorted-by-column
 //   pinv,qinv      inverse permutations (-1 = not pivoted); prow,pcol = pivot row / column of stage k
-//   cbeg..cval     column file (index + value), rbeg..ridx row file (index only); colmax = col_pivot
-//   c/r f/blink    count lists, same representation as src/lu/list.rs (heads at m+nz), 2m+2 entries
+//   crec, rrec     LINE RECORDS, one 32-byte LineRec per column / row: begin, length, capacity of the line in its arena
+//                  (cidx/cval: column file, index + value; ridx: row file, index only), its two count-list links and --
+//                  columns -- its maximum (colmax = col_pivot).  One record = half a 64-byte sector: what a pivot needs
+//                  of a line comes with ONE access instead of five or six gathers from as many arrays (round 4; the
+//                  gathers were ~45 KB of sectors per small pivot against 11 KB algorithmic).  The kernels read and
+//                  write the fields through the views cbeg / clen / ccap / cflink / cblink / colmax, rbeg / rlen / rcap /
+//                  rflink / rblink of DevG / DevGP (RecField, LinkField below), or take whole records (crec[j]).
+//   chead, rhead   heads of the count lists, m+2 HeadRecs each: list nz is element m+nz of the link space, exactly the
+//                  representation of src/lu/list.rs (an element's links live in its record, a head's links here)
 //   rowmark,colmark,iw2   all-zero scratch of the general pivot paths
 //   tnew,tnewr,txrj,tmask per pivot-row column / pivot-column row results of the general pivot paths
 //   gwork          16 * (m+1) doubles: pivot_any dense work columns
@@ -112,18 +119,34 @@ struct Scalars {
 // copies of B, and the scratch of the general pivot paths (see DevGP below).
 #define DEVLU_ARRAYS_HOT(X)                                                                            \
     X(int, pinv) X(int, qinv) X(int, prow) X(int, pcol)                                                \
-    X(int, cbeg) X(int, clen) X(int, ccap) X(int, cidx) X(double, cval)                                \
-    X(int, rbeg) X(int, rlen) X(int, rcap) X(int, ridx) X(double, colmax)                              \
-    X(int, cflink) X(int, cblink)                                                                      \
+    X(LineRec, crec) X(LineRec, rrec) X(HeadRec, chead) X(HeadRec, rhead)                              \
+    X(int, cidx) X(double, cval) X(int, ridx)                                                          \
     X(int, lbeg) X(int, ubeg) X(int, lidx) X(int, uidx) X(double, lval) X(double, uval)
 #define DEVLU_ARRAYS_COLD(X)                                                                           \
     X(const unsigned long long, b_begin) X(const unsigned long long, b_end) X(const unsigned long long, b_i) \
     X(const double, b_x)                                                                               \
     X(int, bc_ptr) X(int, bc_idx) X(double, bc_val) X(int, bt_ptr) X(int, bt_idx) X(double, bt_val)    \
-    X(int, rflink) X(int, rblink)                                                                      \
     X(int, rowmark) X(int, colmark) X(int, tnew) X(int, tnewr) X(double, txrj)                         \
     X(unsigned long long, tmask) X(double, gwork) X(int, iw0) X(int, iw1) X(int, iw2)
 #define DEVLU_ARRAYS(X) DEVLU_ARRAYS_HOT(X) DEVLU_ARRAYS_COLD(X)
+
+// One line (column or row) of the active submatrix; `max` is used by columns only (colmax).
+struct __attribute__((aligned(32))) LineRec {
+    int beg, len, cap;   // the line's entries are arena[beg .. beg+len), room for cap
+    int flink, blink;    // count-list links (list.rs), element space 0..m-1, heads m..2m+1
+    int spare;
+    double max;          // columns: maximum |value| of the column (col_pivot); the pivot once the column is pivotal
+};
+struct __attribute__((aligned(8))) HeadRec {
+    int flink, blink;
+};
+static_assert(sizeof(LineRec) == 32 && sizeof(HeadRec) == 8, "record layout");
+#define LINEREC_BEG 0
+#define LINEREC_LEN 4
+#define LINEREC_CAP 8
+#define LINEREC_FLINK 12
+#define LINEREC_BLINK 16
+#define LINEREC_MAX 24
 
 // The descriptor as the host fills it and as it lives in HBM: plain (generic) pointers.
 struct DevLU {
@@ -144,6 +167,43 @@ struct DevLU {
 typedef GPTR(int) gint_p;
 typedef GPTR(const int) gcint_p;
 typedef GPTR(double) gdouble_p;
+// Views of the line records that index like the arrays they replace: D.cbeg[j] is crec[j].beg, and so on.
+template <class T, int OFF> struct RecField {
+    GPTR(char) base; // the LineRec array
+    __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](int i) const
+    {
+        return *(GPTR(T))(base + (size_t)(unsigned)i * sizeof(LineRec) + OFF);
+    }
+};
+// count-list links over the link space of list.rs: elements 0..m-1 (their records), heads m..2m+1 (the HeadRec array)
+template <int OFF, int HOFF> struct LinkField {
+    GPTR(char) rec;  // the LineRec array
+    GPTR(char) head; // the HeadRec array
+    int m;
+    __device__ __forceinline__ __attribute__((address_space(1))) int &operator[](int x) const
+    {
+        GPTR(char) p = x < m ? rec + (size_t)(unsigned)x * sizeof(LineRec) + OFF : head + (size_t)(unsigned)(x - m) * sizeof(HeadRec) + HOFF;
+        return *(GPTR(int))p;
+    }
+};
+typedef RecField<int, LINEREC_BEG> RecBeg;
+typedef RecField<int, LINEREC_LEN> RecLen;
+typedef RecField<int, LINEREC_CAP> RecCap;
+typedef RecField<double, LINEREC_MAX> RecMax;
+typedef LinkField<LINEREC_FLINK, 0> LinkF;
+typedef LinkField<LINEREC_BLINK, 4> LinkB;
+#define DEV_LINE_VIEWS                                                                                   \
+    RecBeg cbeg, rbeg;                                                                                   \
+    RecLen clen, rlen;                                                                                   \
+    RecCap ccap, rcap;                                                                                   \
+    RecMax colmax;                                                                                       \
+    LinkF cflink, rflink;                                                                                \
+    LinkB cblink, rblink;
+#define DEV_LINE_VIEWS_INIT                                                                              \
+    cbeg{(GPTR(char))crec}, rbeg{(GPTR(char))rrec}, clen{(GPTR(char))crec}, rlen{(GPTR(char))rrec},      \
+        ccap{(GPTR(char))crec}, rcap{(GPTR(char))rrec}, colmax{(GPTR(char))crec},                        \
+        cflink{(GPTR(char))crec, (GPTR(char))chead, m}, rflink{(GPTR(char))rrec, (GPTR(char))rhead, m},  \
+        cblink{(GPTR(char))crec, (GPTR(char))chead, m}, rblink{(GPTR(char))rrec, (GPTR(char))rhead, m}
 // atomics on global-address-space pointers (the HIP atomicAdd/atomicMin overloads take generic pointers)
 __device__ __forceinline__ int g_atomic_add(gint_p p, int v)
 {
@@ -161,6 +221,7 @@ struct DevG {
     DEVLU_ARRAYS(X)
 #undef X
     Scalars *s;
+    DEV_LINE_VIEWS
     __device__ __forceinline__ explicit DevG(const DevLU &d)
         :
 #define X(T, n) n(d.n),
@@ -169,7 +230,8 @@ struct DevG {
 #define X(T, n) n((GPTR(T))d.n),
               DEVLU_ARRAYS(X)
 #undef X
-                  s(d.s)
+                  s(d.s),
+          DEV_LINE_VIEWS_INIT
     {
     }
 };
@@ -198,6 +260,7 @@ struct DevGP {
     DEVLU_ARRAYS_COLD(X)
 #undef X
     Scalars *s;
+    DEV_LINE_VIEWS
     __device__ __forceinline__ explicit DevGP(const DevLU *d)
         :
 #define X(T, n) n(d->n),
@@ -209,7 +272,8 @@ struct DevGP {
 #define X(T, n) n{(const __attribute__((address_space(1))) ColdArr<T>::ptr_t *)&d->n},
                   DEVLU_ARRAYS_COLD(X)
 #undef X
-                      s(d->s)
+                      s(d->s),
+          DEV_LINE_VIEWS_INIT
     {
     }
 };

@@ -302,10 +302,7 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     };
     want(&D.bc_ptr, M + 1); want(&D.bt_ptr, M + 1);
     want(&D.pinv, M); want(&D.qinv, M); want(&D.prow, M + 1); want(&D.pcol, M + 1);
-    want(&D.cbeg, M); want(&D.clen, M); want(&D.ccap, M);
-    want(&D.rbeg, M); want(&D.rlen, M); want(&D.rcap, M);
-    want(&D.colmax, M);
-    want(&D.cflink, 2 * M + 2); want(&D.cblink, 2 * M + 2); want(&D.rflink, 2 * M + 2); want(&D.rblink, 2 * M + 2);
+    want(&D.crec, M); want(&D.rrec, M); want(&D.chead, M + 2); want(&D.rhead, M + 2); // line records, count-list heads (blu_dev.h)
     want(&D.rowmark, M); want(&D.colmark, M);
     want(&D.tnew, M + 2); want(&D.tnewr, M + 2); want(&D.txrj, M + 2); want(&D.tmask, M + 2);
     want(&D.iw0, M + 2); want(&D.iw1, M + 2); want(&D.iw2, M + 2);
@@ -361,6 +358,8 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
             if ((size_t)prop.sharedMemPerBlock >= (size_t)want + 4096 &&
                 hipFuncSetAttribute((const void *)k_prep<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
                 hipFuncSetAttribute((const void *)k_finish<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_prep<512>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_finish<512>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
                 hipFuncSetAttribute((const void *)k_setup, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
                 h->lds_window = want;
             if (lb && h->lds_window) {
@@ -1040,6 +1039,17 @@ template <class T> static bool d2h_vec(blu_hip *h, std::vector<T> &v, const T *d
     if (!n) return true;
     return hip_ok(h, hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost), "d2h dbg");
 }
+// the line records and list heads of a handle on the host (debug dumps)
+struct HostLines {
+    std::vector<LineRec> crec, rrec;
+    std::vector<HeadRec> chead, rhead;
+};
+static bool d2h_lines(blu_hip *h, HostLines &L)
+{
+    const size_t M = (size_t)h->m;
+    return d2h_vec(h, L.crec, h->D.crec, M) && d2h_vec(h, L.rrec, h->D.rrec, M) && d2h_vec(h, L.chead, h->D.chead, M + 2) &&
+           d2h_vec(h, L.rhead, h->D.rhead, M + 2);
+}
 // which: 0 column-file entries, 1 row-file entries, 2 L entries so far, 3 U entries so far
 extern "C" int64_t blu_hip_dbg_count(blu_hip *h, int which)
 {
@@ -1048,10 +1058,10 @@ extern "C" int64_t blu_hip_dbg_count(blu_hip *h, int which)
     if (!download_scalars(h)) return -1;
     if (which == 2) return h->hs.lused;
     if (which == 3) return h->hs.uused;
-    std::vector<int> len;
-    if (!d2h_vec(h, len, which ? h->D.rlen : h->D.clen, (size_t)h->m)) return -1;
+    std::vector<LineRec> rec;
+    if (!d2h_vec(h, rec, which ? h->D.rrec : h->D.crec, (size_t)h->m)) return -1;
     int64_t n = 0;
-    for (int64_t k = 0; k < h->m; k++) n += len[k];
+    for (int64_t k = 0; k < h->m; k++) n += rec[k].len;
     return n;
 }
 // same layout as oracle/orc_debug.c: orc_dbg_active_state
@@ -1063,13 +1073,22 @@ extern "C" int blu_hip_dbg_active_state(blu_hip *h, int64_t *colptr, int64_t *co
     (void)hipSetDevice(h->device);
     const size_t M = (size_t)h->m;
     DevLU &D = h->D;
-    std::vector<int> cbeg, clen, rbeg, rlen, cidx, ridx, pi, qi, cf, cb, rf, rb;
+    std::vector<int> cbeg(M), clen(M), rbeg(M), rlen(M), cidx, ridx, pi, qi, cf(2 * M + 2), cb(2 * M + 2), rf(2 * M + 2), rb(2 * M + 2);
     std::vector<double> cval;
-    bool ok = d2h_vec(h, cbeg, D.cbeg, M) && d2h_vec(h, clen, D.clen, M) && d2h_vec(h, rbeg, D.rbeg, M) && d2h_vec(h, rlen, D.rlen, M);
+    HostLines HL;
+    bool ok = d2h_lines(h, HL);
+    if (ok) { // the arrays of list.rs / file.rs out of the records: elements 0..m-1, heads m..2m+1
+        for (size_t j = 0; j < M; j++) {
+            cbeg[j] = HL.crec[j].beg; clen[j] = HL.crec[j].len; rbeg[j] = HL.rrec[j].beg; rlen[j] = HL.rrec[j].len;
+            cf[j] = HL.crec[j].flink; cb[j] = HL.crec[j].blink; rf[j] = HL.rrec[j].flink; rb[j] = HL.rrec[j].blink;
+            colmax[j] = HL.crec[j].max;
+        }
+        for (size_t k = 0; k < M + 2; k++) {
+            cf[M + k] = HL.chead[k].flink; cb[M + k] = HL.chead[k].blink; rf[M + k] = HL.rhead[k].flink; rb[M + k] = HL.rhead[k].blink;
+        }
+    }
     ok = ok && d2h_vec(h, cidx, D.cidx, (size_t)D.carena_cap) && d2h_vec(h, cval, D.cval, (size_t)D.carena_cap) && d2h_vec(h, ridx, D.ridx, (size_t)D.rarena_cap);
     ok = ok && d2h_vec(h, pi, D.pinv, M) && d2h_vec(h, qi, D.qinv, M);
-    ok = ok && d2h_vec(h, cf, D.cflink, 2 * M + 2) && d2h_vec(h, cb, D.cblink, 2 * M + 2) && d2h_vec(h, rf, D.rflink, 2 * M + 2) && d2h_vec(h, rb, D.rblink, 2 * M + 2);
-    ok = ok && hip_ok(h, hipMemcpy(colmax, D.colmax, M * 8, hipMemcpyDeviceToHost), "d2h colmax");
     if (!ok) return BLU_ERROR_DEVICE;
     int64_t put = 0;
     for (size_t j = 0; j < M; j++) {

@@ -129,7 +129,8 @@ __device__ void scope_sort_segment(Scope &sc, long long *key, double *val, int b
 // else by insertion_sort_pairs
 template <bool REGSORT, class Scope>
 __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, Scope &sc, double *shd, int *lds_k, double *lds_v,
-                                            int *win = nullptr, int wincap = 0) // (win: an LDS window for the column counters, see prep_body)
+                                            int *win = nullptr, int wincap = 0, // (win: an LDS window for the column counters, see prep_body)
+                                            int nslice = 1 << 30)              // (waves of a workgroup that have a sort slice in lds_k / lds_v)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -210,11 +211,12 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sc.sync();
-        for (int r = sc.wid(); r < nmed; r += sc.nw()) {
-            const int k = D.iw2[r];
-            wave_sort_segment(O.l_rowidx, O.l_value, D.lbeg[k] + k + 1, D.lbeg[k + 1] + k + 1, &lds_k[wave_id() * WSORT_MAX],
-                              &lds_v[wave_id() * WSORT_MAX]);
-        }
+        if (wave_id() < nslice)
+            for (int r = sc.wid(); r < nmed; r += sc.nw()) {
+                const int k = D.iw2[r];
+                wave_sort_segment(O.l_rowidx, O.l_value, D.lbeg[k] + k + 1, D.lbeg[k + 1] + k + 1, &lds_k[wave_id() * WSORT_MAX],
+                                  &lds_v[wave_id() * WSORT_MAX]);
+            }
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = D.lbeg[k] + k + 1, e = D.lbeg[k + 1] + k + 1;
@@ -355,11 +357,12 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sc.sync();
-        for (int r = sc.wid(); r < nmed; r += sc.nw()) {
-            const int k = D.iw2[r];
-            const int b = (int)O.u_colptr[k];
-            wave_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], &lds_k[wave_id() * WSORT_MAX], &lds_v[wave_id() * WSORT_MAX]);
-        }
+        if (wave_id() < nslice)
+            for (int r = sc.wid(); r < nmed; r += sc.nw()) {
+                const int k = D.iw2[r];
+                const int b = (int)O.u_colptr[k];
+                wave_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], &lds_k[wave_id() * WSORT_MAX], &lds_v[wave_id() * WSORT_MAX]);
+            }
         for (int r = 0; r < nlong; r++) {
             const int k = D.iw2[m - 1 - r];
             const int b = (int)O.u_colptr[k];
@@ -376,19 +379,21 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         S->u_nz = u_tot - m;
     }
 }
-// NT = threads of the workgroup at most (256: a batch; 1024: one matrix without a cooperative launch)
+// NT = threads of the workgroup at most (256 or 512: a batch -- two waves per SIMD still leave a thread the 200-250
+// registers of the register sorts; 1024: one matrix without a cooperative launch)
 template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, FinishOut *Os, int nmat, int winbytes)
 {
     BLU_DYN_SHARED(unsigned char, finish_win, 144 * 1024); // (the counter window: winbytes of dynamic LDS, or none)
     __shared__ int sh[40];
     __shared__ long long shl[20];
     __shared__ double shd[40];
-    __shared__ int lds_k[NT / 64 * WSORT_MAX];
-    __shared__ double lds_v[NT / 64 * WSORT_MAX];
+    constexpr int NSLICE = NT == 512 ? 4 : NT / 64; // (512 threads: sort slices for four of the eight waves -- the window takes the rest of the LDS)
+    __shared__ int lds_k[NSLICE * WSORT_MAX];
+    __shared__ double lds_v[NSLICE * WSORT_MAX];
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) { // (see k_prep)
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        finish_body<NT <= 256>(D, Os[b], sc, shd, lds_k, lds_v, winbytes > 0 ? (int *)finish_win : nullptr, winbytes / 4);
+        finish_body<NT <= 512>(D, Os[b], sc, shd, lds_k, lds_v, winbytes > 0 ? (int *)finish_win : nullptr, winbytes / 4, NSLICE);
         __syncthreads();
     }
 }
@@ -418,7 +423,9 @@ __global__ void __launch_bounds__(1024) k_compact(DevLU *Ds, const int *whichv, 
     __shared__ int sh[40];
     const int tid = threadIdx.x, nt = blockDim.x, w = wave_id(), nw = num_waves(), lane = lane_id();
     const int m = D.m;
-    gint_p beg = which ? D.rbeg : D.cbeg, len = which ? D.rlen : D.clen, cap = which ? D.rcap : D.ccap;
+    const RecBeg beg = which ? D.rbeg : D.cbeg;
+    const RecLen len = which ? D.rlen : D.clen;
+    const RecCap cap = which ? D.rcap : D.ccap;
     gcint_p old_idx = which ? D.ridx : D.cidx;
     int *nidx = new_idx[blockIdx.x];
     double *nval = which ? nullptr : new_val[blockIdx.x];

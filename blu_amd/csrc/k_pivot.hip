@@ -114,7 +114,7 @@ struct alignas(16) Sm {
 // ------------------------------------------------------------------------------------------------
 // list primitives (src/lu/list.rs), single-lane versions
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void list_remove1(gint_p flink, gint_p blink, int e)
+__device__ __forceinline__ void list_remove1(const LinkF &flink, const LinkB &blink, int e)
 {
     const int f = flink[e], b = blink[e];
     flink[b] = f;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void list_remove1(gint_p flink, gint_p blink, int e)
     flink[e] = e;
     blink[e] = e;
 }
-__device__ __forceinline__ void list_add1(int e, int list, gint_p flink, gint_p blink, int nelem)
+__device__ __forceinline__ void list_add1(int e, int list, const LinkF &flink, const LinkB &blink, int nelem)
 {
     const int t = blink[nelem + list];
     blink[nelem + list] = e;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void list_add1(int e, int list, gint_p flink, gint_p 
 // elem(q) / key(q) are read through the two arrays with the given offsets; key < 0 = not moved.
 // `mark` is an all-zero int[m] scratch (restored to zero).  Returns min key > 0 (or big).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_list_move_batch(gint_p flink, gint_p blink, int nelem, gcint_p elems, gcint_p keys, int n,
+__device__ __forceinline__ int wave_list_move_batch(const LinkF &flink, const LinkB &blink, int nelem, gcint_p elems, gcint_p keys, int n,
                                                     gint_p mark, int big)
 {
     const int lane = lane_id();

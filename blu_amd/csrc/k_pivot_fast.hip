@@ -157,7 +157,8 @@ struct LinksC {
 };
 // the same interface over two plain arrays (row count lists)
 struct LinksG {
-    gint_p f, b;
+    LinkF f;
+    LinkB b;
     __device__ __forceinline__ int fl(int e) const { return f[e]; }
     __device__ __forceinline__ int bl(int e) const { return b[e]; }
     __device__ __forceinline__ void set_fl(int e, int v) const { f[e] = v; }

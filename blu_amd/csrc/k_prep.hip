@@ -18,7 +18,7 @@
 // ---------------------------------------------------------------------------------------------
 // The lists are independent of each other, so the waves of the scope share them out: wave `part` of `nparts`
 // builds the lists with key % nparts == part (every wave scans all elements; the keys are read coalesced).
-__device__ int wave_list_build(gint_p flink, gint_p blink, int n, gcint_p keys, int big, int part, int nparts)
+__device__ int wave_list_build(const LinkF &flink, const LinkB &blink, int n, gcint_p keys, int big, int part, int nparts)
 {
     const int lane = lane_id();
     int minkey = big;
@@ -455,7 +455,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
 }
 // One workgroup per matrix AT A TIME: the grid is smaller than a large batch and each workgroup takes matrices
 // blockIdx.x, + gridDim.x, ... (blu_driver.inc: batch_grid).
-// NT = threads of the workgroup at most (256: a batch; 1024: one matrix without a cooperative launch)
+// NT = threads of the workgroup at most (256 or 512: a batch; 1024: one matrix without a cooperative launch)
 // winbytes = dynamic LDS of the launch (the window of prep_body), 0: none
 template <int NT> __global__ void __launch_bounds__(NT) k_prep(DevLU *Ds, int nmat, int winbytes)
 {
@@ -465,7 +465,7 @@ template <int NT> __global__ void __launch_bounds__(NT) k_prep(DevLU *Ds, int nm
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) {
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        prep_body<NT <= 256>(D, sc, winbytes > 0 ? (int *)prep_win : nullptr, winbytes / 4);
+        prep_body<NT <= 512>(D, sc, winbytes > 0 ? (int *)prep_win : nullptr, winbytes / 4);
         __syncthreads();
     }
 }

@@ -366,7 +366,7 @@ template <int NT> __global__ void __launch_bounds__(NT) k_stats_tail(DevLU *Ds, 
                 chain_out[1] = S->normest_u_inv;
             }
             __syncthreads();
-            stats_tail<NT <= 256>(D, Os[b], red, chain_out);
+            stats_tail<NT <= 512>(D, Os[b], red, chain_out);
             const size_t ng = (size_t)7 * (D.m + 1);
             for (size_t e = threadIdx.x; e < ng; e += blockDim.x) D.gwork[e] = 0.0;
         }
