@@ -185,6 +185,16 @@ template <int OFF, int HOFF> struct LinkField {
         GPTR(char) p = x < m ? rec + (size_t)(unsigned)x * sizeof(LineRec) + OFF : head + (size_t)(unsigned)(x - m) * sizeof(HeadRec) + HOFF;
         return *(GPTR(int))p;
     }
+    // the same where the caller knows what x is: an element (x < m) / the head of list k (x = m + k) -- no select, and an
+    // element's link then merges with the other fields of its record into one wide load
+    __device__ __forceinline__ __attribute__((address_space(1))) int &el(int x) const
+    {
+        return *(GPTR(int))(rec + (size_t)(unsigned)x * sizeof(LineRec) + OFF);
+    }
+    __device__ __forceinline__ __attribute__((address_space(1))) int &hd(int k) const
+    {
+        return *(GPTR(int))(head + (size_t)(unsigned)k * sizeof(HeadRec) + HOFF);
+    }
 };
 typedef RecField<int, LINEREC_BEG> RecBeg;
 typedef RecField<int, LINEREC_LEN> RecLen;

@@ -170,8 +170,8 @@ __device__ __forceinline__ void mc_reset(const DevGP &D, Mc *mc, int first, int 
 {
     for (int k = first; k < MC_HEADS; k += step) {
         const bool in = k <= D.m + 1;
-        mc->hf[k] = in ? D.cflink[D.m + k] : 0;
-        mc->hb[k] = in ? D.cblink[D.m + k] : 0;
+        mc->hf[k] = in ? D.cflink.hd(k) : 0;
+        mc->hb[k] = in ? D.cblink.hd(k) : 0;
     }
     if (first == 0) {
         mc->dirty = 0;
@@ -537,7 +537,7 @@ __device__ __forceinline__ int mk_walk(const DevGP &D, Sm *sm, Mc *mc)
                     cl = fa->tNew[ps];
                     cmx = fa->tMx[ps];
                 } else {
-                    fl = D.cflink[j];
+                    fl = D.cflink.el(j);
                     cb = D.cbeg[j];
                     cl = D.clen[j];
                     cmx = D.colmax[j];
@@ -798,8 +798,8 @@ __device__ __forceinline__ void mk_pick(const DevGP &D, Sm *sm, Mc *mc, long lon
             tl = D.clen[jq0];
             tc = D.ccap[jq0];
 #if !BLU_CFG_BATCH
-            tfl = D.cflink[jq0]; // for the unlink wave: same round trip, one less on its own chain
-            tbl = D.cblink[jq0];
+            tfl = D.cflink.el(jq0); // for the unlink wave: same round trip, one less on its own chain
+            tbl = D.cblink.el(jq0);
 #endif
         }
         int gc = 0, gr = 0;
@@ -1643,7 +1643,7 @@ __device__ __forceinline__ void spec_walk(const DevGP &D, Sm *sm, Mc *mc)
             const int znz = nz + b;
             int guard = 0;
             while (j < m && ncand < K) {
-                const int fl = D.cflink[j], cb = D.cbeg[j], cl = D.clen[j];
+                const int fl = D.cflink.el(j), cb = D.cbeg[j], cl = D.clen[j];
                 const double cmx = D.colmax[j];
                 if (cl != znz || cmx == 0.0 || !(cmx >= D.abstol) || ++guard > m + 2) {
                     bad = true;

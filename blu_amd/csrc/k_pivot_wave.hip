@@ -195,15 +195,15 @@ __device__ __forceinline__ int wv_list_move(const DevGP &D, Fast *fa, int e, int
     const int tfix = __shfl(fp, tl >= 0 ? tl : lane);
     if (act && tl >= 0) t = tfix;
     if (isgone) { // list.rs:84-85: a removed element links to itself
-        D.cflink[e] = e;
-        D.cblink[e] = e;
+        D.cflink.el(e) = e;
+        D.cblink.el(e) = e;
     }
     WAVE_LOCKSTEP(); // unlink stores before append stores (one address may get both; a wave's stores keep their order)
     if (act) {
-        D.cblink[e] = prevl >= 0 ? eprev : t;
-        D.cflink[e] = nextl >= 0 ? enext : m + key;
+        D.cblink.el(e) = prevl >= 0 ? eprev : t;
+        D.cflink.el(e) = nextl >= 0 ? enext : m + key;
         if (prevl < 0) D.cflink[t] = e;
-        if (nextl < 0) D.cblink[m + key] = e;
+        if (nextl < 0) D.cblink.hd(key) = e;
     }
     wave_mem_sync();
     return minall;
@@ -237,7 +237,7 @@ struct WvWalk {
 };
 __device__ __forceinline__ void ew_issue(const DevGP &D, WvWalk &E)
 {
-    E.fl = D.cflink[E.j];
+    E.fl = D.cflink.el(E.j);
     E.cb = D.cbeg[E.j];
     E.cl = D.clen[E.j];
     E.cmx = D.colmax[E.j];
@@ -248,7 +248,7 @@ __device__ __forceinline__ void ew_begin(const DevGP &D, WvWalk &E, int nz0)
     const int m = D.m;
     E.nz0 = nz0;
     const int kk = lane == 0 ? 0 : nz0 + lane - 1;
-    E.h = kk <= m ? D.cflink[m + kk] : m + kk;
+    E.h = kk <= m ? D.cflink.hd(kk) : m + kk;
     E.ne = 0ull;
     E.j = 0;
     E.znz = E.ncand = E.total = E.guard = 0;
@@ -440,8 +440,8 @@ __device__ __forceinline__ bool wv_layout(const DevGP &D, Sm *sm, WvLines &L, Wv
     L.j = lane <= rnz1 ? fa->tJ[lane < rnz1 ? lane + 1 : 0] : -1; // lane rnz1: the pivot column
     L.cb = L.cl = L.cap = L.fl = L.bl = 0;
     if (lane <= rnz1) {
-        L.fl = D.cflink[L.j];
-        L.bl = D.cblink[L.j];
+        L.fl = D.cflink.el(L.j);
+        L.bl = D.cblink.el(L.j);
     }
     if (lane < rnz1) {
         L.cb = D.cbeg[L.j];
@@ -908,7 +908,7 @@ __device__ __forceinline__ void wv_small(const DevGP &D, Sm *sm, const WvLines &
     // tails of the columns' new count lists: the keys are final here, the lists are not touched until the list move
     // below -- the load stays in flight over the whole row file update
     int ltail = 0;
-    if (lane < rnz1) ltail = D.cblink[D.m + newlen];
+    if (lane < rnz1) ltail = D.cblink.hd(newlen);
 
     WV_T(10);
     // ================= row file update (pivot.rs:695-775) =================
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ void wv_scol(const DevGP &D, Sm *sm, const WvLines &L
     wave_mem_sync();
     // tails of the columns' new count lists (every column loses exactly one entry): in flight over the pass below
     int ltail = 0;
-    if (lane < rnz1) ltail = D.cblink[D.m + L.cl - 1];
+    if (lane < rnz1) ltail = D.cblink.hd(L.cl - 1);
     WV_T(18);
     int cbv = -1;
     for (int k = 0; k * 64 < Tc; k++) {
