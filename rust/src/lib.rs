@@ -4,9 +4,11 @@
 //! with `use blu_hip::BLU`.
 //!
 //! What differs, and why:
-//! * `BLU.lu` is not a struct of arrays in host memory (all state of the factorization lives in HBM): it is a
-//!   handle with the reference's public parameter fields as setter / getter pairs (`lu().set_droptol(..)`,
-//!   `lu().droptol()`; `src/lu/lu.rs:11-66`) and its getters (`src/lu/lu.rs:398-684`) under the same names.
+//! * `BLU.lu` is a public field as in the reference (`blu.rs:10`), but `struct LU` is not a struct of arrays in host
+//!   memory (all state of the factorization lives in HBM): it owns the device handle and has the reference's public
+//!   parameter fields as setter / getter pairs (`blu.lu.set_droptol(..)`, `blu.lu.droptol()`; `src/lu/lu.rs:11-66`)
+//!   and its getters (`src/lu/lu.rs:398-684`) under the same names.  `BLU.realloc_factor` is a plain public field
+//!   (`blu.rs:18-20`), handed to the library before every call that may grow storage.
 //! * `Status::Reallocate` never reaches the caller of the object API in the reference either
 //!   (`blu.rs:105-115, 277-283, 324-330`); the library grows its device storage itself.
 //! * Two more error values exist: `ErrorDevice` (a HIP call failed, `last_error()` has the text) and
@@ -126,10 +128,9 @@ mod key {
     pub const UPDATE_COST: i32 = 124;
 }
 
-/// The part of `struct LU` (`src/lu/lu.rs`) a user of the object API touches: parameters and getters.
-pub struct LuView<'a> {
+/// `struct LU` (`src/lu/lu.rs`) as a user of the object API sees it: parameters and getters.  Owns the device handle.
+pub struct LU {
     h: *mut BluHip,
-    _owner: std::marker::PhantomData<&'a mut BLU>,
 }
 
 macro_rules! param {
@@ -152,7 +153,7 @@ macro_rules! stat {
     };
 }
 
-impl<'a> LuView<'a> {
+impl LU {
     // public parameter fields, lu.rs:11-66 (defaults lu.rs:249-259)
     param!(droptol, set_droptol, key::DROPTOL, f64);
     param!(abstol, set_abstol, key::ABSTOL, f64);
@@ -209,9 +210,16 @@ impl<'a> LuView<'a> {
     }
 }
 
+impl Drop for LU {
+    fn drop(&mut self) {
+        unsafe { blu_hip_free(self.h) }
+    }
+}
+
 /// `struct BLU` (`src/blu.rs:9-20`).
 pub struct BLU {
-    h: *mut BluHip,
+    /// `pub lu: LU` (`blu.rs:10`).
+    pub lu: LU,
     m: usize,
     /// Solution of the last `solve_sparse` / `solve_for_update` (dense, `m` entries; `blu.rs:12`).
     pub lhs: Vec<f64>,
@@ -219,6 +227,8 @@ pub struct BLU {
     pub ilhs: Vec<LUInt>,
     /// Number of nonzeros in `lhs` (`blu.rs:16`).
     pub nzlhs: usize,
+    /// Arrays are reallocated for max(realloc_factor, 1.0) times the required size (`blu.rs:18-20`, default 1.5).
+    pub realloc_factor: f64,
 }
 
 // The reference's BLU is `Send` (plain owned data); a handle is used by one thread at a time here as well.
@@ -236,23 +246,18 @@ impl BLU {
         if h.is_null() {
             return None;
         }
-        Some(BLU { h, m, lhs: vec![0.0; m], ilhs: vec![0; m], nzlhs: 0 })
+        Some(BLU { lu: LU { h }, m, lhs: vec![0.0; m], ilhs: vec![0; m], nzlhs: 0, realloc_factor: 1.5 })
     }
 
-    /// Parameters and getters of `struct LU` (`self.lu` in the reference).
-    pub fn lu(&mut self) -> LuView<'_> {
-        LuView { h: self.h, _owner: std::marker::PhantomData }
-    }
-
-    /// `BLU.realloc_factor` (`blu.rs:18-20`, default 1.5).
-    pub fn set_realloc_factor(&mut self, f: f64) {
+    // the library grows its device storage itself (the loops of blu.rs:105-115, 277-283, 324-330): it gets the factor
+    fn push_realloc_factor(&mut self) {
         unsafe {
-            blu_hip_set_param(self.h, key::REALLOC_FACTOR, f);
+            blu_hip_set_param(self.lu.h, key::REALLOC_FACTOR, self.realloc_factor);
         }
     }
 
     pub fn last_error(&self) -> String {
-        unsafe { CStr::from_ptr(blu_hip_last_error(self.h)).to_string_lossy().into_owned() }
+        unsafe { CStr::from_ptr(blu_hip_last_error(self.lu.h)).to_string_lossy().into_owned() }
     }
 
     /// `BLU::factorize` (`blu.rs:95-118`): column j of B is `b_i[b_begin[j]..b_end[j]]`, `b_x[..]`.
@@ -260,10 +265,11 @@ impl BLU {
         if b_begin.len() < self.m || b_end.len() < self.m || b_i.len() != b_x.len() {
             return Err(Status::ErrorInvalidArgument);
         }
+        self.push_realloc_factor();
         // usize == u64 on the targets this back end exists for (x86-64 Linux hosts of MI355X nodes)
         let code = unsafe {
             blu_hip_factorize(
-                self.h, b_begin.as_ptr() as *const u64, b_end.as_ptr() as *const u64, b_i.as_ptr() as *const u64, b_x.as_ptr(), b_i.len() as u64,
+                self.lu.h, b_begin.as_ptr() as *const u64, b_end.as_ptr() as *const u64, b_i.as_ptr() as *const u64, b_x.as_ptr(), b_i.len() as u64,
             )
         };
         status_of(code)
@@ -280,7 +286,7 @@ impl BLU {
             o.map(|s| s.as_mut_ptr()).unwrap_or(std::ptr::null_mut())
         }
         let code = unsafe {
-            blu_hip_get_factors(self.h, p(rowperm), p(colperm), p(l_colptr), p(l_rowidx), p(l_value), p(u_colptr), p(u_rowidx), p(u_value))
+            blu_hip_get_factors(self.lu.h, p(rowperm), p(colperm), p(l_colptr), p(l_rowidx), p(l_value), p(u_colptr), p(u_rowidx), p(u_value))
         };
         status_of(code)
     }
@@ -290,12 +296,12 @@ impl BLU {
         if rhs.len() < self.m || lhs.len() < self.m {
             return Err(Status::ErrorInvalidArgument);
         }
-        status_of(unsafe { blu_hip_solve_dense(self.h, rhs.as_ptr(), lhs.as_mut_ptr(), trans as c_char) })
+        status_of(unsafe { blu_hip_solve_dense(self.lu.h, rhs.as_ptr(), lhs.as_mut_ptr(), trans as c_char) })
     }
 
     // lu_clear_lhs, blu.rs:380-395
     fn clear_lhs(&mut self) {
-        let nzsparse = (self.lu().sparse_thres() * self.m as f64) as usize;
+        let nzsparse = (self.lu.sparse_thres() * self.m as f64) as usize;
         if self.nzlhs != 0 {
             if self.nzlhs <= nzsparse {
                 for p in 0..self.nzlhs {
@@ -318,7 +324,7 @@ impl BLU {
         let mut nz: i64 = 0;
         let code = unsafe {
             blu_hip_solve_sparse(
-                self.h, nzrhs, irhs.as_ptr() as *const u64, xrhs.as_ptr(), &mut nz, self.ilhs.as_mut_ptr(), self.lhs.as_mut_ptr(), trans as c_char,
+                self.lu.h, nzrhs, irhs.as_ptr() as *const u64, xrhs.as_ptr(), &mut nz, self.ilhs.as_mut_ptr(), self.lhs.as_mut_ptr(), trans as c_char,
             )
         };
         status_of(code)?;
@@ -335,16 +341,17 @@ impl BLU {
             return Err(Status::ErrorInvalidArgument);
         }
         self.clear_lhs();
+        self.push_realloc_factor();
         let xp = xrhs.map(|x| x.as_ptr()).unwrap_or(std::ptr::null());
         let mut nz: i64 = 0;
         let code = unsafe {
             if want_solution != 0 {
                 blu_hip_solve_for_update(
-                    self.h, nzrhs as i64, irhs.as_ptr() as *const u64, xp, &mut nz, self.ilhs.as_mut_ptr(), self.lhs.as_mut_ptr(), trans as c_char,
+                    self.lu.h, nzrhs as i64, irhs.as_ptr() as *const u64, xp, &mut nz, self.ilhs.as_mut_ptr(), self.lhs.as_mut_ptr(), trans as c_char,
                 )
             } else {
                 blu_hip_solve_for_update(
-                    self.h, nzrhs as i64, irhs.as_ptr() as *const u64, xp, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(),
+                    self.lu.h, nzrhs as i64, irhs.as_ptr() as *const u64, xp, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(),
                     trans as c_char,
                 )
             }
@@ -358,13 +365,8 @@ impl BLU {
 
     /// `BLU::update` (`blu.rs:319-335`).
     pub fn update(&mut self, xtbl: f64) -> Result<(), Status> {
-        status_of(unsafe { blu_hip_update(self.h, xtbl) })
-    }
-}
-
-impl Drop for BLU {
-    fn drop(&mut self) {
-        unsafe { blu_hip_free(self.h) }
+        self.push_realloc_factor();
+        status_of(unsafe { blu_hip_update(self.lu.h, xtbl) })
     }
 }
 

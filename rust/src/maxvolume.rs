@@ -74,7 +74,7 @@ fn run(
         obj.update(xtbl)?;
         // refactorize when the eta file is full, the update was inaccurate, or solving has become expensive
         let (nforrest, piverr, cost) = {
-            let lu = obj.lu();
+            let lu = &obj.lu;
             (lu.nforrest(), lu.pivot_error(), lu.update_cost())
         };
         if nforrest == m || piverr > 1e-8 || cost > 1.0 {

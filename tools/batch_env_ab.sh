@@ -5,6 +5,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 OUT=gpurun_out/batch_env_ab.log; : > $OUT
 for a in "$@"; do
   IFS=: read cfg B k hd ev <<< "$a"
-  env BLU_PIVOT_KERNEL=$k $(echo ${ev:-X=1} | tr , ' ') timeout -k 10 300 python tools/batch_probe.py $B 256 $cfg ${hd:-2} 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/$cfg $ev /" >> $OUT || exit 1
+  env BLU_PIVOT_KERNEL=$k $(echo ${ev:-X=1} | tr , ' ') timeout -k 10 300 python tools/batch_probe.py $B 256 $cfg ${hd:-2} 2>&1 | grep -v amdgpu.ids | tail -1 | awk -v p="$cfg $ev " '{print p $0}' >> $OUT || exit 1
 done
 cat $OUT

@@ -28,4 +28,5 @@ for rep in range(reps):
           (B, block, os.environ.get("BLU_PIVOT_KERNEL", "default"), rep, el, nnz / el / 1e6, tp, hs[0].stat(K.STAT_DEV_RELAUNCHES),
            (32 * F + 32 * lu) / tp / 1e9, (32 * F + 32 * lu) / tp / 1e9 / 80.0, ph[0], ph[1], ph[2], ph[3],
            hs[0].stat(110), hs[0].stat(111), hs[0].stat(54), hs[0].stat(52)), "handed", hs[0].stat(116),
-          "free mem %.1f GB" % (torch.cuda.mem_get_info()[0] / 1e9), flush=True)
+          "free mem %.1f GB" % (torch.cuda.mem_get_info()[0] / 1e9),
+          "arena used c/r %d/%d of cap %d; L cap %d" % (max(h.stat(112) for h in hs), max(h.stat(113) for h in hs), hs[0].stat(114), hs[0].stat(115)), flush=True)
