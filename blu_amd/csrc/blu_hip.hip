@@ -327,9 +327,9 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
     h->batch_block = 256;
     {   // diagnostic: which pivot kernel this handle launches (read once; blu_hip_dbg_set_pivot_kernel overrides)
         const char *bo = getenv("BLU_BATCH_OTHER"), *bs = getenv("BLU_BATCH_STATS");
-        h->batch_block_other = bo ? atoi(bo) : 256;
+        h->batch_block_other = bo ? atoi(bo) : 512; // (512 = two waves per SIMD with the registers of the register sorts: 8-15 % faster than 256, round 4)
         h->batch_block_stats = bs ? atoi(bs) : 256;
-        if (h->batch_block_other < 64 || h->batch_block_other > 1024 || (h->batch_block_other & 63)) h->batch_block_other = 256;
+        if (h->batch_block_other < 64 || h->batch_block_other > 1024 || (h->batch_block_other & 63)) h->batch_block_other = 512;
         if (h->batch_block_stats < 64 || h->batch_block_stats > 1024 || (h->batch_block_stats & 63)) h->batch_block_stats = 256;
         h->no_out_alias = getenv("BLU_NO_OUT_ALIAS") ? 1 : 0;
         const char *pk = getenv("BLU_PIVOT_KERNEL");

@@ -69,6 +69,38 @@ __device__ __forceinline__ void small_sort_pairs(long long *key, double *val, in
     }
 }
 
+// L column k of the canonical factors in ONE pass for a column of at most SSORT_MAX entries: stage entries and their new
+// row numbers (pinv) into registers, rank there, store every pair where it belongs -- the unsorted copy that small_sort_pairs
+// reads back and rewrites never goes through memory (k_finish of a batch is bound by its HBM sector traffic: round 4).
+__device__ __forceinline__ void small_sort_gather(gcint_p lidx, gdouble_p lval, gcint_p pinv, int b, int e, long long *okey, double *oval, int ob)
+{
+    const int n = e - b;
+    int k[SSORT_MAX];
+    double v[SSORT_MAX];
+#pragma unroll
+    for (int i = 0; i < SSORT_MAX; i++) {
+        k[i] = 0x7fffffff; // (new row numbers are < 2^31 - 1: the padding is never below a key)
+        v[i] = 0.0;
+        if (i < n) {
+            k[i] = lidx[b + i];
+            v[i] = lval[b + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SSORT_MAX; i++)
+        if (i < n) k[i] = pinv[k[i]];
+#pragma unroll
+    for (int i = 0; i < SSORT_MAX; i++) {
+        if (i < n) {
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < SSORT_MAX; j++) r += (k[j] < k[i]) ? 1 : 0;
+            okey[ob + r] = k[i];
+            oval[ob + r] = v[i];
+        }
+    }
+}
+
 // Rank sort of one segment [b,e) of at most WSORT_MAX pairs by ONE wave, staged through this wave's
 // LDS slice (keys distinct).  Each lane ranks its elements against the whole segment.
 #define WSORT_MAX 256
@@ -180,6 +212,10 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int ob = b + k;
         O.l_rowidx[ob] = k;
         O.l_value[ob] = 1.0;
+        if (REGSORT && e - b <= SSORT_MAX) { // (nearly every column of an LP basis: renumbered and sorted in registers, written once)
+            small_sort_gather(D.lidx, D.lval, D.pinv, b, e, O.l_rowidx, O.l_value, ob + 1);
+            continue;
+        }
         // (four entries per turn: their loads -- index, then the gather through pinv -- are in flight together; a thread
         // walking its line entry by entry is a chain of dependent round trips, and one workgroup per CU hides none)
         int p = b;
@@ -211,8 +247,10 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sc.sync();
-        if (wave_id() < nslice)
-            for (int r = sc.wid(); r < nmed; r += sc.nw()) {
+        // (a 512-thread workgroup of a batch has sort slices for `nslice` of its waves only: those share out the segments)
+        const bool limited = nslice < num_waves();
+        if (!limited || wave_id() < nslice)
+            for (int r = sc.wid(); r < nmed; r += limited ? nslice : sc.nw()) {
                 const int k = D.iw2[r];
                 wave_sort_segment(O.l_rowidx, O.l_value, D.lbeg[k] + k + 1, D.lbeg[k + 1] + k + 1, &lds_k[wave_id() * WSORT_MAX],
                                   &lds_v[wave_id() * WSORT_MAX]);
@@ -357,8 +395,9 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sc.sync();
-        if (wave_id() < nslice)
-            for (int r = sc.wid(); r < nmed; r += sc.nw()) {
+        const bool limited = nslice < num_waves();
+        if (!limited || wave_id() < nslice)
+            for (int r = sc.wid(); r < nmed; r += limited ? nslice : sc.nw()) {
                 const int k = D.iw2[r];
                 const int b = (int)O.u_colptr[k];
                 wave_sort_segment(O.u_rowidx, O.u_value, b, b + D.iw0[k], &lds_k[wave_id() * WSORT_MAX], &lds_v[wave_id() * WSORT_MAX]);

@@ -392,11 +392,21 @@ __global__ void __launch_bounds__(64) k_solve_upd(DevLU *Ds, SparseWs W, UpdWs U
             const int ipivot = U.eta_row[t];
             const int b = U.rbeg[t], e = U.rbeg[t + 1];
             double x = 0.0; // the same on every lane
+            // the ordered sum of solve_for_update.rs:312-329, without its zero terms: the vector is a sparse spike, a row eta
+            // of a banded basis has tens of thousands of entries, and x + (+-0.0) == x bit for bit (x starts as +0.0 and a
+            // round-to-nearest sum is -0.0 only if both operands are) -- so only the lanes with a nonzero product take part,
+            // in lane order (was: 64 dependent adds through ds_bpermute per chunk, most of the forward solve's time)
             for (int c = b; c < e; c += 64) {
                 const int p = c + lane;
-                const double term = p < e ? __dmul_rn(W.work[U.ridx[p]], U.rval[p]) : 0.0;
-                const int cnt = min(64, e - c);
-                for (int q = 0; q < cnt; q++) x = __dadd_rn(x, __shfl(term, q)); // ordered sum
+                const int pp = p < e ? p : b; // (every lane loads: no load under a branch)
+                const double w = W.work[U.ridx[pp]], rv = U.rval[pp];
+                const double term = p < e ? __dmul_rn(w, rv) : 0.0;
+                unsigned long long nzb = __ballot(term != 0.0); // (a NaN counts as nonzero)
+                while (nzb) {
+                    const int q = __ffsll((long long)nzb) - 1;
+                    nzb &= nzb - 1;
+                    x = __dadd_rn(x, wave_bcast_d(term, q));
+                }
             }
             const bool fresh = x != 0.0 && W.marked[ipivot] != M;
             wave_mem_sync();
