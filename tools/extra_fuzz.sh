@@ -1,0 +1,18 @@
+#!/bin/bash
+# Sweeps of FRESH seeds outside the suite (run once on the final build of a round; results into gpurun_out/extra_fuzz.log):
+# single bases on all three batch-capable pivot kernels, random batches (default dispatch and one-wave kernel forced),
+# mid-size and large bases, the update path.  Each tool runs as a child with a timeout; a failure stops the script.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+set -o pipefail
+L=gpurun_out/extra_fuzz.log; : > $L; n=0
+run() { n=$((n+1)); echo "== $*" >> $L; timeout -k 10 ${T:-500} "$@" --log gpurun_out/extra_fuzz_$n.log 2>&1 | grep -v amdgpu.ids | tail -2 >> $L || { echo "FAILED: $*" >> $L; tail -5 $L; exit 1; }; }
+run python tools/fuzz_gpu.py --seed 40401 --count 500
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed 40402 --count 300
+BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed 40403 --count 300
+run python tools/fuzz_gpu.py --seed 40404 --count 40 --mmin 3000 --mmax 20000
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed 40405 --count 25 --mmin 3000 --mmax 20000
+BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed 40406 --count 25 --mmin 3000 --mmax 20000
+run python tools/fuzz_batch_gpu.py --seed 40407 --count 40
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_batch_gpu.py --seed 40408 --count 25
+run python tools/fuzz_update_gpu.py --seed 40409 --count 120
+cat $L
