@@ -108,3 +108,15 @@ def test_batch_with_two_workgroups_on_the_cpu(emu_lib):
 def test_general_paths_on_the_cpu(emu_lib):
     """the general pivot paths alone (no flattened paths), as a workgroup of one wave"""
     assert run_child(emu_lib, [(220, 8, 8, 0.5, 1, 0.3)], kernel=1, no_fast=True) == 0
+
+
+def test_step_check_of_the_line_records_on_the_cpu(emu_lib):
+    """tools/gpu_stepcheck.py under the emulation build: the library is stopped every 25 pivots and its COMPLETE active
+    submatrix -- ordered line contents, column maxima, the count lists with their heads, pivots, partial L / U: what the
+    32-byte line records (blu_dev.h: LineRec, HeadRec) hold, read out through blu_hip_dbg_active_state -- is compared with
+    the oracle's arrays (file.rs / list.rs representation), for the one-wave kernel and for the general paths."""
+    for extra, kernel in ((["--block", "64"], "1"), (["--block", "64", "--no-fast"], "1"), (["--block", "128"], "3")):
+        env = dict(os.environ, BLU_HIP_LIB=emu_lib, BLU_PIVOT_KERNEL=kernel)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_stepcheck.py"), "160,7,8,0.5,0.3,3", "--step", "25"] + extra,
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "FACTORS IDENTICAL" in out.stdout and "MISMATCH" not in out.stdout, out.stdout[-2500:] + out.stderr[-2500:]
