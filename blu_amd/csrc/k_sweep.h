@@ -5,6 +5,17 @@
 
 typedef GPTR(const long long) gcll_p;
 typedef GPTR(const double) gcdouble_p;
+// What a sweep step reads at a WAVE-UNIFORM address -- the column pointers of the step, its pivot, its pivot row -- goes
+// through the SCALAR data path: pointers into the constant address space make the compiler emit s_load_* for them.  As
+// vector loads (all 64 lanes, one address) they went through the CU's vector memory pipeline, which the sweep chains of
+// a batch -- 24 waves per CU, seven loads per step -- are bound by (round 4: neither a deeper look-ahead nor fewer ALU
+// instructions changed k_stats; loads issued by every lane instead of the column's lanes made it 30 % slower).  The factors
+// are read-only in these kernels (written by earlier launches), so the scalar cache holds nothing stale.
+#ifdef BLU_EMU_BUILD
+#define SWEEP_UNIFORM(T, p) (p)
+#else
+#define SWEEP_UNIFORM(T, p) ((__attribute__((address_space(4))) const T *)(p))
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Pipelined triangular sweeps.  A sweep is a chain of m dependent steps: step k reads entries of the
@@ -33,14 +44,14 @@ struct UCols {
     {
         ColPtr P;
         k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = colptr[k];
-        P.e = colptr[k + 1] - 1;
+        P.b = SWEEP_UNIFORM(long long, colptr)[k];
+        P.e = SWEEP_UNIFORM(long long, colptr)[k + 1] - 1;
         P.diag = 0.0;
         P.aux = 0;
         P.aux2 = 0;
         return P;
     }
-    __device__ __forceinline__ void diag(ColPtr &P) const { P.diag = value[P.e]; }
+    __device__ __forceinline__ void diag(ColPtr &P) const { P.diag = SWEEP_UNIFORM(double, value)[P.e]; }
     __device__ __forceinline__ ColEnt ent(const ColPtr &P, long long off) const
     {
         ColEnt E;
@@ -63,8 +74,8 @@ struct LCols {
     {
         ColPtr P;
         k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = colptr[k] + 1;
-        P.e = colptr[k + 1];
+        P.b = SWEEP_UNIFORM(long long, colptr)[k] + 1;
+        P.e = SWEEP_UNIFORM(long long, colptr)[k + 1];
         P.diag = 1.0;
         P.aux = 0;
         P.aux2 = 0;
@@ -94,10 +105,10 @@ struct LStage {
     {
         ColPtr P;
         k = k < 0 ? 0 : (k >= m ? m - 1 : k);
-        P.b = lbeg[k];
-        P.e = lbeg[k + 1];
+        P.b = SWEEP_UNIFORM(int, lbeg)[k];
+        P.e = SWEEP_UNIFORM(int, lbeg)[k + 1];
         P.diag = 1.0;
-        P.aux = prow[k];
+        P.aux = SWEEP_UNIFORM(int, prow)[k];
         P.aux2 = 0;
         return P;
     }
