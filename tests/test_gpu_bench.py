@@ -25,3 +25,19 @@ def test_bench_under_torch_distributed_run_world_size_one():
     assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["workload"].startswith("C4") and rec["roofline"]["bound"] == "hbm"
     assert "process group: nccl" in out.stderr + out.stdout
+
+
+def test_bench_batched_leg_verifies_its_members():
+    """The secondary (batched) measurement of bench.py end to end on a small batch: 64 distinct matrices with per-handle
+    device inputs, cold step + three warm steps, and -- after the timed steps -- eight members checked against the CPU
+    oracle (`verified_members`); the roofline object of the leg names the batch pivot kernel the library chose."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "2", "--warmup", "1", "--batch", "300",
+           "--no-batch-sizes", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    b = rec["batched"]
+    assert b["bases_in_flight_per_gpu"] == 300 and b["distinct_matrices"] == 64 and b["verified_members"] == 8
+    assert len(b["seconds_warm_steps"]) == 3 and b["cold_first_step"]["seconds"] > 0
+    assert "k_pivot_loop_wave2" in b["roofline"]["kernel"] and 0 < b["roofline"]["frac"] < 1
+    assert rec["config"]["generator_note"].startswith("bw = 8, not SURVEY.md 8d's provisional 16")  # (C2 is lp_basis(10 000, 8, bw 8, ...))
