@@ -48,10 +48,10 @@ def _check_member(h, o, tag):
         assert h.stat(51 + kind) == o.stat(51 + kind), (tag, "pivots of kind", kind)
     for c in FSTATS:
         assert h.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), (tag, c)
-    assert h.stat(50) == 0 and o.d3_hits() == 0, tag
+    assert int(h.stat(50)) == o.d3_hits(), tag  # (reference defect D3: 0 on both sides unless the test allows such a matrix)
 
 
-def _batch_as_benched(blu, oracle, cfg, n, nseeds, step, expect_kernel):
+def _batch_as_benched(blu, oracle, cfg, n, nseeds, step, expect_kernel, allow_d3=False):
     c = CONFIGS[cfg]
     mats = [blu.gen_lp_basis(c["m"], c["k"], c["bw"], c["tri_frac"], 5000 + s, c["offscale"]) for s in range(nseeds)]
     oracles = {}
@@ -59,7 +59,9 @@ def _batch_as_benched(blu, oracle, cfg, n, nseeds, step, expect_kernel):
     def oracle_of(s):
         if s not in oracles:
             cp, ri, v = mats[s]
-            o, so = util.oracle_factorize(oracle, cp, ri, v, cap=16 * len(ri))  # faithful mask, asserts d3_hits == 0
+            # the FAITHFUL restatement (i32 cancellation mask, defect D3) with d3_hits == 0 asserted; allow_d3: a matrix that does
+            # hit D3 (the reference has no defined result there) is checked against the 64-bit-mask oracle instead
+            o, so = util.oracle_factorize(oracle, cp, ri, v, cap=16 * len(ri), allow_d3=allow_d3)
             assert so == K.OK
             oracles[s] = o
         return oracles[s]
@@ -110,3 +112,10 @@ def test_c4_size_batch_two_wave_kernel_natural_window(blu, oracle):
     """320 C4-size bases: every workgroup resident -> k_pivot_loop_wave2 (the kernel behind the C3-size leg), at least one
     basis per CU -> the natural LDS window of k_prep / k_finish, several 36 864-line windows per matrix."""
     _batch_as_benched(blu, oracle, "C4", 320, 32, 9, expect_kernel=3)
+
+
+def test_c3_size_batch_two_wave_kernel(blu, oracle):
+    """256 bases of the 100k size (BASELINE.json's headline configuration; bench.py times 1536 of them and verifies eight):
+    one basis per CU -> the natural LDS window with three windows per matrix, k_pivot_loop_wave2; 32 distinct seeds, 33
+    members compared in full, every member's counters."""
+    _batch_as_benched(blu, oracle, "C3", 256, 32, 8, expect_kernel=3, allow_d3=True)  # (one of the 32 seeds hits D3 at this size)
