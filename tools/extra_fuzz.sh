@@ -6,13 +6,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 set -o pipefail
 L=gpurun_out/extra_fuzz.log; : > $L; n=0
 run() { n=$((n+1)); echo "== $*" >> $L; timeout -k 10 ${T:-500} "$@" --log gpurun_out/extra_fuzz_$n.log 2>&1 | grep -v amdgpu.ids | tail -2 >> $L || { echo "FAILED: $*" >> $L; tail -5 $L; exit 1; }; }
-run python tools/fuzz_gpu.py --seed 40401 --count 500
-BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed 40402 --count 300
-BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed 40403 --count 300
-run python tools/fuzz_gpu.py --seed 40404 --count 40 --mmin 3000 --mmax 20000
-BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed 40405 --count 25 --mmin 3000 --mmax 20000
-BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed 40406 --count 25 --mmin 3000 --mmax 20000
-run python tools/fuzz_batch_gpu.py --seed 40407 --count 40
-BLU_PIVOT_KERNEL=1 run python tools/fuzz_batch_gpu.py --seed 40408 --count 25
-run python tools/fuzz_update_gpu.py --seed 40409 --count 120
+run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 1)) --count 500
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 2)) --count 300
+BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 3)) --count 300
+run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 4)) --count 40 --mmin 3000 --mmax 20000
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 5)) --count 25 --mmin 3000 --mmax 20000
+BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 6)) --count 25 --mmin 3000 --mmax 20000
+run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 7)) --count 40
+BLU_PIVOT_KERNEL=1 run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 8)) --count 25
+run python tools/fuzz_update_gpu.py --seed $((${SEED0:-40400} + 9)) --count 120
 cat $L
