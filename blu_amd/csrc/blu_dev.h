@@ -60,7 +60,7 @@ struct Scalars {
     int lused, uused;     // L / U entries written
     int need;             // entries requested by a NEED_* exit
     int l_nz, u_nz;       // final counts (build_factors)
-    int pad0;
+    int fill_paths;       // (diagnostic) bit 0 / bit 1: the transposing fill of k_prep / k_finish went through buckets (k_bucket.h)
     long long matrix_nz;
     long long bump_nz;
     long long nsearch_pivot;

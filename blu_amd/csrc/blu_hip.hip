@@ -523,6 +523,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 114: return (double)h->D.carena_cap;
     case 115: return (double)h->D.lcap;
     case 118: return (double)h->last_pivot_kernel; // which pivot kernel the last factorize of this handle ran: 0 k_pivot_loop, 1 k_pivot_loop_wave, 2 k_pivot_loop_batch, 3 k_pivot_loop_wave2
+    case 119: return (double)s.fill_paths; // bit 0 / bit 1: k_prep / k_finish filled through buckets (k_bucket.h)
     case 57: return (double)s.err_line;
     case 58: return (double)s.status;
     case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75:

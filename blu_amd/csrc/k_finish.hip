@@ -10,6 +10,7 @@
 //   k_compact = file_compress (src/lu/file.rs:92-135) for the bump-pointer arenas: lines are copied
 //               in index order into a fresh arena with stretch*len+pad room each.
 #include "blu_dev.h"
+#include "k_bucket.h"
 
 struct FinishOut {
     long long *rowperm, *colperm;             // m
@@ -162,7 +163,8 @@ __device__ void scope_sort_segment(Scope &sc, long long *key, double *val, int b
 template <bool REGSORT, class Scope>
 __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, Scope &sc, double *shd, int *lds_k, double *lds_v,
                                             int *win = nullptr, int wincap = 0, // (win: an LDS window for the column counters, see prep_body)
-                                            int nslice = 1 << 30)              // (waves of a workgroup that have a sort slice in lds_k / lds_v)
+                                            int nslice = 1 << 30,              // (waves of a workgroup that have a sort slice in lds_k / lds_v)
+                                            char *fscr = nullptr, long long fscr_bytes = 0) // (this workgroup's scratch for the fill through buckets, k_bucket.h)
 {
     Scalars *S = D.s;
     const int tid = sc.tid(), nt = sc.nt();
@@ -268,17 +270,52 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     // (build_factors.rs:318-337, `qinv[j] < rank`)
     for (int k = tid; k < m; k += nt) D.iw0[k] = 0;
     sc.sync();
+    // (a batch: the target column qinv[uidx[p]] of every entry is a gather; the first sweep leaves it in the workgroup's
+    // scratch, ctgt[p], and the later sweeps read that in place of index + gather.  Counters of one byte hold every column of
+    // the matrix in ONE window (147 456 columns), so the count is a single sweep; a column of 255 or more entries sends the
+    // matrix to the 32-bit windows.)
+    const int unz4 = (D.ubeg[rank] + 3) & ~3;
+    const bool keep_c = win && fscr && 20LL * unz4 <= fscr_bytes; // (uniform; 4 bytes per target + 16 per record of the fill)
+    int *ctgt = (int *)fscr;
+    bool have_c = false;
+    const auto colof = [&](int p) { return have_c ? ctgt[p] : D.qinv[D.uidx[p]]; };
     if (win) { // column counts through the LDS window
-        for (int w0 = 0; w0 < rank; w0 += wincap) {
+        bool counted = false;
+        if (rank <= 4 * wincap) {
+            unsigned *winb = (unsigned *)win;
+            for (int i = tid; i < (rank + 3) / 4; i += nt) winb[i] = 0;
+            sc.sync();
+            int ovf = 0;
+            for (int k = tid; k < rank; k += nt)
+                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return D.qinv[D.uidx[p]]; },
+                      [&](int p, int c) {
+                          if (keep_c) ctgt[p] = c;
+                          if (c < rank) {
+                              const int sh = (c & 3) * 8;
+                              const unsigned was = atomicAdd(&winb[c >> 2], 1u << sh);
+                              ovf |= ((was >> sh) & 255u) == 255u;
+                          }
+                      });
+            have_c = keep_c;
+            ovf = sc.any(ovf); // (a barrier: every counter is final behind it)
+            if (!ovf) {
+                for (int i = tid; i < rank; i += nt) D.iw0[i] = (int)((winb[i >> 2] >> ((i & 3) * 8)) & 255u);
+                counted = true;
+            }
+            sc.sync();
+        }
+        for (int w0 = 0; !counted && w0 < rank; w0 += wincap) {
             const int wn = rank - w0 < wincap ? rank - w0 : wincap;
+            const bool put_c = keep_c && !have_c; // (the first sweep over the entries)
             for (int i = tid; i < wn; i += nt) win[i] = 0;
             sc.sync();
             for (int k = tid; k < rank; k += nt)
-                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return D.qinv[D.uidx[p]]; },
-                      [&](int, int c) {
-                          const unsigned d = (unsigned)(c - w0);
-                          if (d < (unsigned)wn) atomicAdd(&win[d], 1);
-                      });
+                line4(D.ubeg[k], D.ubeg[k + 1], colof, [&](int p, int c) {
+                    if (put_c) ctgt[p] = c;
+                    const unsigned d = (unsigned)(c - w0);
+                    if (d < (unsigned)wn) atomicAdd(&win[d], 1);
+                });
+            have_c = keep_c;
             sc.sync();
             for (int i = tid; i < wn; i += nt) D.iw0[w0 + i] = win[i];
             sc.sync();
@@ -320,13 +357,43 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         *sc.ctr(0) = *sc.ctr(1) = 0;
     }
     sc.sync();
-    if (win) { // column cursors in the LDS window
+    // the fill of a batch in two phases (k_bucket.h): the records behind the targets in the workgroup's scratch
+    bool bucketed = false;
+    if (win && have_c) {
+        static_assert(BKT_SSORT == SSORT_MAX, "lines the buckets leave sorted = lines the pass below skips");
+        Buckets BK = buckets_in(win, wincap);
+        if (buckets_plan(sc, BK, D.iw1, m, u_tot)) {
+            BktRec *scr = (BktRec *)(fscr + 4LL * unz4);
+            buckets_open(sc, BK, D.iw1, m, 1);
+            for (int k = tid; k < rank; k += nt)
+                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return IdxVal{0, ctgt[p], D.uval[p]}; },
+                      [&](int, const IdxVal &a) {
+                          if (a.g < rank) bucket_put(BK, scr, a.g, k, a.v);
+                      });
+            sc.sync();
+            for (int b = 0; b < BK.nb; b++)
+                bucket_flush(
+                    sc, BK, b, D.iw1, m, u_tot, 1, scr,
+                    [&](int t, int *key, double *val) { // pivot last
+                        *key = t;
+                        *val = D.colmax[D.pcol[t]];
+                    },
+                    [&](int pos, int key, double val) {
+                        O.u_rowidx[pos] = key;
+                        O.u_value[pos] = val;
+                    });
+            bucketed = true;
+            if (sc.leader()) S->fill_paths |= 2;
+        }
+    }
+    if (bucketed) {
+    } else if (win) { // column cursors in the LDS window
         for (int w0 = 0; w0 < rank; w0 += wincap) {
             const int wn = rank - w0 < wincap ? rank - w0 : wincap;
             for (int i = tid; i < wn; i += nt) win[i] = D.iw1[w0 + i];
             sc.sync();
             for (int k = tid; k < rank; k += nt)
-                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return IdxVal{0, D.qinv[D.uidx[p]], D.uval[p]}; },
+                line4(D.ubeg[k], D.ubeg[k + 1], [&](int p) { return IdxVal{0, colof(p), D.uval[p]}; },
                       [&](int, const IdxVal &a) {
                           const unsigned d = (unsigned)(a.g - w0);
                           if (d < (unsigned)wn) {
@@ -381,12 +448,15 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     for (int k = tid; k < m; k += nt) {
         const int b = (int)O.u_colptr[k], e = b + D.iw0[k];
         const double piv = D.colmax[D.pcol[k]];
-        O.u_rowidx[e] = k; // pivot last
-        O.u_value[e] = piv;
+        if (!bucketed) {
+            O.u_rowidx[e] = k; // pivot last
+            O.u_value[e] = piv;
+        }
         pmin = fmin(pmin, fabs(piv));
         pmax = fmax(pmax, fabs(piv));
         if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(sc.ctr(1), 1)] = k;
         else if (e - b > SSORT_MAX) D.iw2[atomicAdd(sc.ctr(0), 1)] = k;
+        else if (bucketed) continue; // (sorted in LDS before it was written)
         else if (REGSORT) small_sort_pairs(O.u_rowidx, O.u_value, b, e);
         else insertion_sort_pairs(O.u_rowidx, O.u_value, b, e);
     }
@@ -420,7 +490,8 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
 }
 // NT = threads of the workgroup at most (256 or 512: a batch -- two waves per SIMD still leave a thread the 200-250
 // registers of the register sorts; 1024: one matrix without a cooperative launch)
-template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, FinishOut *Os, int nmat, int winbytes)
+// fscr: scratch of fscr_bytes per workgroup for the fill through buckets, or null
+template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, FinishOut *Os, int nmat, int winbytes, char *fscr, long long fscr_bytes)
 {
     BLU_DYN_SHARED(unsigned char, finish_win, 144 * 1024); // (the counter window: winbytes of dynamic LDS, or none)
     __shared__ int sh[40];
@@ -432,7 +503,8 @@ template <int NT> __global__ void __launch_bounds__(NT) k_finish(DevLU *Ds, Fini
     for (int b = blockIdx.x; b < nmat; b += gridDim.x) { // (see k_prep)
         const DevG D(Ds[b]);
         BlockScope sc{sh, shl};
-        finish_body<NT <= 512>(D, Os[b], sc, shd, lds_k, lds_v, winbytes > 0 ? (int *)finish_win : nullptr, winbytes / 4, NSLICE);
+        finish_body<NT <= 512>(D, Os[b], sc, shd, lds_k, lds_v, winbytes > 0 ? (int *)finish_win : nullptr, winbytes / 4, NSLICE,
+                               fscr ? fscr + (long long)blockIdx.x * fscr_bytes : nullptr, fscr_bytes);
         __syncthreads();
     }
 }

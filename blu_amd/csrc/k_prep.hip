@@ -10,6 +10,7 @@
 // count / scan / ordered-fill passes that produce the same order of entries and the same
 // order of elements in the count lists (ascending index inside a list, list.rs:65-70).
 #include "blu_dev.h"
+#include "k_bucket.h"
 
 // ---------------------------------------------------------------------------------------------
 // ordered tail-append of elements 0..n-1 (ascending) into count lists by key, ONE wave.
@@ -138,6 +139,13 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         return;
     }
     for (int i = tid; i < m; i += nt) D.iw0[i] = 0;
+    // (a window that holds every row as a counter of one byte: the rows are counted while the columns are packed; a row of
+    // 255 or more entries sends the matrix to the sweeps with 32-bit windows below)
+    const bool bytes = win && m <= 4 * wincap; // (uniform)
+    unsigned *winb = (unsigned *)win;
+    if (bytes)
+        for (int i = tid; i < (m + 3) / 4; i += nt) winb[i] = 0;
+    int ovf = 0;
     sc.sync();
 
     // ---- count nz per row, check indices, pack columns (singletons.rs:152-173)
@@ -148,7 +156,13 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
             if (i >= (unsigned long long)m) {
                 bad = 1;
             } else {
-                if (!win) g_atomic_add(&D.iw0[(int)i], 1);
+                if (!win) {
+                    g_atomic_add(&D.iw0[(int)i], 1);
+                } else if (bytes) {
+                    const int sh = ((int)i & 3) * 8;
+                    const unsigned was = atomicAdd(&winb[(int)i >> 2], 1u << sh);
+                    ovf |= ((was >> sh) & 255u) == 255u;
+                }
                 D.bc_idx[put] = (int)i;
                 D.bc_val[put] = x;
             }
@@ -170,7 +184,16 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         if (sc.leader()) set_error(S, ST_INVALID_ARG, __LINE__);
         return;
     }
-    if (win) { // row counts through the LDS window
+    bool counted = false;
+    if (bytes) {
+        ovf = sc.any(ovf);
+        if (!ovf) {
+            for (int i = tid; i < m; i += nt) D.iw0[i] = (int)((winb[i >> 2] >> ((i & 3) * 8)) & 255u);
+            counted = true;
+        }
+        sc.sync();
+    }
+    if (win && !counted) { // row counts through the LDS window
         for (int r0 = 0; r0 < m; r0 += wincap) {
             const int wn = m - r0 < wincap ? m - r0 : wincap;
             for (int i = tid; i < wn; i += nt) win[i] = 0;
@@ -205,7 +228,33 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
 
     // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
     // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
-    if (win) { // fill cursors in the LDS window
+    // a batch: in two phases through buckets (k_bucket.h); the 16-byte records go to the value array of the column arena
+    // (nothing is in the arenas before k_setup)
+    bool bucketed = false;
+    if (win) {
+        static_assert(BKT_SSORT == 32, "rows the buckets leave sorted = rows the pass below skips");
+        Buckets BK = buckets_in(win, wincap);
+        const bool room = 2LL * b_nz <= (long long)D.carena_cap; // (uniform)
+        if (room && buckets_plan(sc, BK, D.iw1, m, b_nz)) {
+            BktRec *scr = (BktRec *)D.cval;
+            buckets_open(sc, BK, D.iw1, m, 0);
+            for (int j = tid; j < m; j += nt)
+                line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
+                      [&](int, const IdxVal &a) { bucket_put(BK, scr, a.i, j, a.v); });
+            sc.sync();
+            for (int b = 0; b < BK.nb; b++)
+                bad |= bucket_flush(
+                    sc, BK, b, D.iw1, m, b_nz, 0, scr, [&](int, int *, double *) {},
+                    [&](int pos, int key, double val) {
+                        D.bt_idx[pos] = key;
+                        D.bt_val[pos] = val;
+                    });
+            bucketed = true;
+            if (sc.leader()) S->fill_paths |= 1;
+        }
+    }
+    if (bucketed) {
+    } else if (win) { // fill cursors in the LDS window
         for (int r0 = 0; r0 < m; r0 += wincap) {
             const int wn = m - r0 < wincap ? m - r0 : wincap;
             for (int i = tid; i < wn; i += nt) win[i] = D.iw1[r0 + i];
@@ -241,6 +290,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
             D.iw2[k] = i; // list of long rows (order irrelevant)
             continue;
         }
+        if (bucketed && e - b <= 32) continue; // (sorted and checked for duplicates in LDS before it was written)
         if (REGSORT && e - b <= 16) {
             reg_sort_row<16>(D.bt_idx, D.bt_val, b, e - b);
         } else if (REGSORT && e - b <= 32) {

@@ -51,6 +51,7 @@ for g, (cp, ri, v), s in zip(hs, mats, st):
         assert g.stat(51 + kind) == o.stat(51 + kind), ("pivot kind", kind)
     assert int(g.stat(50)) == o.d3_hits()
     fast += int(g.stat(110)) + int(g.stat(111))
+print("FILLS", " ".join(str(int(g.stat(119))) for g in hs))
 print("FAST", fast)
 """
 
@@ -62,11 +63,13 @@ def emu_lib():
     return EMU
 
 
-def run_child(emu_lib, spec, kernel, no_fast=False, extra_env=None):
+def run_child(emu_lib, spec, kernel, no_fast=False, extra_env=None, fills=None):
     env = dict(os.environ, BLU_HIP_LIB=emu_lib, BLU_PIVOT_KERNEL=str(kernel), **(extra_env or {}))
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "spec": spec, "no_fast": no_fast}], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    if fills is not None:  # statistic 119 of every handle: which of k_prep (1) / k_finish (2) filled through buckets
+        assert [int(x) for x in out.stdout.split("FILLS")[-1].split("FAST")[0].split()] == fills, out.stdout[-500:]
     return int(out.stdout.split("FAST")[-1])
 
 
@@ -103,6 +106,17 @@ def test_batch_with_two_workgroups_on_the_cpu(emu_lib):
     fast = run_child(emu_lib, [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6), (120, 6, 6, 0.5, 4, 0.3),
                                (260, 7, 9, 0.3, 5, 0.5)], kernel=0, extra_env={"BLU_BATCH_GRID": "2", "BLU_LDS_WINDOW": "2", "BLU_LDS_WINDOW_BYTES": "1024"})
     assert fast > 400
+
+
+def test_batch_fills_through_buckets_on_the_cpu(emu_lib):
+    """the two-phase fill of k_prep / k_finish (k_bucket.h) with a window of 16 KB: buckets of 672 entries, so every one of
+    these matrices is several buckets (the fourth has a U column of 112 entries, longer than the 96 a bucket keeps as slack:
+    its k_finish takes the window sweeps); the 1 KB windows of the test above are too small for buckets (statistic 119 == 0)"""
+    specs = [(200, 8, 8, 0.5, 1, 0.3), (333, 8, 8, 0.5, 2, 0.3), (150, 5, 4, 0.8, 3, 0.6), (420, 9, 12, 0.3, 4, 0.3), (260, 7, 9, 0.3, 5, 0.5)]
+    env = {"BLU_BATCH_GRID": "2", "BLU_LDS_WINDOW": "2"}
+    fast = run_child(emu_lib, specs, kernel=0, extra_env=dict(env, BLU_LDS_WINDOW_BYTES="16384"), fills=[3, 3, 3, 1, 3])
+    assert fast > 600
+    run_child(emu_lib, specs[:2], kernel=0, extra_env=dict(env, BLU_LDS_WINDOW_BYTES="1024"), fills=[0, 0])
 
 
 def test_general_paths_on_the_cpu(emu_lib):

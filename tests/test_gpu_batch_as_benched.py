@@ -74,6 +74,8 @@ def _batch_as_benched(blu, oracle, cfg, n, nseeds, step, expect_kernel, allow_d3
         sts = blu.factorize_batch(hs, mats=member_mats)  # no debug environment, default dispatch
         assert all(s == K.OK for s in sts), (what, [(k, s) for k, s in enumerate(sts) if s != K.OK][:8])
         assert int(hs[0].stat(118)) == expect_kernel and int(hs[-1].stat(118)) == expect_kernel, what
+        if what == "hint nnz/2":  # as benched: k_prep and k_finish fill through buckets (k_bucket.h; statistic 119)
+            assert all(int(h.stat(119)) == 3 for h in hs), what
         for k in sample:
             _check_member(hs[k], oracle_of(k % nseeds), "%s %s member %d (seed %d)" % (cfg, what, k, 5000 + k % nseeds))
         # every member: the counters that cost one call each, against the oracle run of its seed (run for the sample

@@ -358,19 +358,22 @@ def test_batch_of_independent_bases(blu, oracle):
     assert hs[0].factorize(mats[0][0][:-1], mats[0][0][1:], mats[0][1], mats[0][2]) == K.OK
 
 
-def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch):
+@pytest.mark.parametrize("window", [2048, 16384, 49152], ids=["2KB-windows", "16KB-buckets", "48KB-buckets"])
+def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch, window):
     """The O(nnz) kernels of a batch (k_prep, k_setup, k_finish, k_stats_tail) run a fixed number of workgroups, each
     taking matrix after matrix (one per CU: a large batch).  Here 3 workgroups for 8 bases of different sizes (the
     grid is read when a handle is created), so every workgroup goes through several matrices with the same LDS; and the
     row / column counters of k_prep / k_finish go through their LDS window (a large batch: 144 KB), forced here and cut
-    down to 2 KB so that every matrix takes several windows: factors, counters and all statistics of every member as the
+    down to 2 KB so that every matrix takes several windows; with 16 KB and 48 KB the fills of k_prep / k_finish go through
+    buckets of 672 / 2576 entries (k_bucket.h; statistic 119 says which did: a matrix with a line longer than a bucket's
+    slack takes the windows), several to dozens per matrix: factors, counters and all statistics of every member as the
     oracle has them."""
     specs = [(300, 5, 4, 0.5, 1, 0.3), (1200, 8, 8, 0.5, 2, 0.3), (150, 4, 3, 0.5, 3, 0.3), (2000, 8, 8, 0.5, 4, 0.3),
              (700, 6, 6, 1.0, 5, 0.2), (900, 7, 8, 0.5, 21, 0.4), (400, 6, 6, 0.0, 13, 0.5), (2500, 10, 9, 0.5, 1, 0.3)]
     mats = [oracle.gen_lp_basis(*s) for s in specs]
     monkeypatch.setenv("BLU_BATCH_GRID", "3")
     monkeypatch.setenv("BLU_LDS_WINDOW", "2")
-    monkeypatch.setenv("BLU_LDS_WINDOW_BYTES", "2048")
+    monkeypatch.setenv("BLU_LDS_WINDOW_BYTES", str(window))
     hs = [blu.BLU(len(cp) - 1, len(ri)) for cp, ri, v in mats]
     for name in ("BLU_BATCH_GRID", "BLU_LDS_WINDOW", "BLU_LDS_WINDOW_BYTES"):
         monkeypatch.delenv(name)
@@ -385,6 +388,8 @@ def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch):
             for c in FSTATS + ("RESIDUAL_TEST", "MIN_PIVOT", "MAX_PIVOT"):
                 assert h.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), (k, c)
             assert int(h.stat(118)) == 3  # a batch this small: two waves per basis (k_pivot_loop_wave2)
+        fills = [int(h.stat(119)) for h in hs]
+        assert fills == [0] * 8 if window == 2048 else (all(f & 1 for f in fills) and sum(f == 3 for f in fills) >= 4), fills
 
 
 @pytest.mark.parametrize("spec", [(3000, 9, 10, 0.4, 17, 0.4), (2500, 10, 9, 0.5, 1, 0.3), (1800, 6, 30, 0.1, 9, 1.0)],
