@@ -25,6 +25,26 @@
 #ifndef BLU_DYN_SHARED
 #define BLU_DYN_SHARED(T, name, bytes) extern __shared__ __attribute__((aligned(16))) T name[]
 #endif
+// Diagnostic build (-DBLU_PROFILE_FILLS, `make fprof`; tools/fill_phases.py): thread 0 of a workgroup of k_prep / k_finish adds
+// the shader-clock ticks since its previous stamp to Scalars::prof[k].  The product build contains no stamps.
+#ifdef BLU_PROFILE_FILLS
+#define FILL_STAMP_BEGIN() long long fill_t0_ = (long long)__builtin_amdgcn_s_memtime()
+#define FILL_STAMP(S, k)                                                 \
+    do {                                                                 \
+        if (threadIdx.x == 0) {                                          \
+            const long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
+            (S)->prof[k] += t_ - fill_t0_;                               \
+            fill_t0_ = t_;                                               \
+        }                                                                \
+    } while (0)
+#else
+#define FILL_STAMP_BEGIN() \
+    do {                   \
+    } while (0)
+#define FILL_STAMP(S, k) \
+    do {                 \
+    } while (0)
+#endif
 // occupancy hint of a kernel (a device-only attribute)
 #ifdef BLU_EMU_BUILD
 #define BLU_WAVES_PER_EU(lo, hi)

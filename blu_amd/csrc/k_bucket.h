@@ -14,8 +14,9 @@
 //
 // LDS (the window of the launch, `wincap` ints):
 //   [0, 1024)            bnd[b] = first target line that starts in bucket b (bnd[nb..] = number of lines)
-//   phase A  [1024, 2048) the bucket cursors; from 2048: tb[g] = bucket of line 64 g (16 bits each)
-//   phase B  from 1024:   `span` values, `span` keys, `span` line cursors
+//   [1024, 1536)         phase B: the lines of the bucket that a whole wave sorts (their number, then start and length)
+//   phase A  [1536, 2560) the bucket cursors; from 2560: tb[g] = bucket of line 64 g (16 bits each)
+//   phase B  from 1536:   `span` values, `span` keys, `span` line cursors
 // A target line may hang over the end of its bucket by its own length: `slack` = span / 8 entries are kept for that, and
 // a matrix with a longer line, more than 1023 buckets or more lines in one bucket than `span` takes the window sweeps.
 #pragma once
@@ -27,6 +28,7 @@ struct alignas(16) BktRec {
 };
 #define BKT_NBMAX 1023
 #define BKT_SSORT 32
+#define BKT_WSORT 256
 
 struct Buckets {
     int span, slack, ch, nb;
@@ -34,7 +36,7 @@ struct Buckets {
     unsigned short *tb;
     int tbcap;
     double *lv;
-    int *lk, *lcur;
+    int *lk, *lcur, *wl;
     __device__ __forceinline__ int of(int t) const
     {
         int b = tb[t >> 6];
@@ -46,17 +48,18 @@ struct Buckets {
 __device__ __forceinline__ Buckets buckets_in(int *win, int wincap)
 {
     Buckets B;
-    B.span = wincap >= 4096 ? ((wincap - 1024) / 4) & ~63 : 0;
+    B.span = wincap >= 4096 ? ((wincap - 1536) / 4) & ~63 : 0;
     B.slack = B.span / 8;
     B.ch = B.span - B.slack;
     B.nb = 0;
     B.bnd = win;
-    B.cur = win + 1024;
-    B.tb = (unsigned short *)(win + 2048);
-    B.tbcap = wincap >= 4096 ? (wincap - 2048) * 2 : 0;
-    B.lv = (double *)(win + 1024);
-    B.lk = win + 1024 + 2 * B.span;
-    B.lcur = win + 1024 + 3 * B.span;
+    B.wl = win + 1024;
+    B.cur = win + 1536;
+    B.tb = (unsigned short *)(win + 2560);
+    B.tbcap = wincap >= 4096 ? (wincap - 2560) * 2 : 0;
+    B.lv = (double *)(win + 1536);
+    B.lk = win + 1536 + 2 * B.span;
+    B.lcur = win + 1536 + 3 * B.span;
     return B;
 }
 
@@ -104,9 +107,59 @@ __device__ __forceinline__ void bucket_put(const Buckets &B, BktRec *scr, int t,
     scr[pos] = r;
 }
 
+// A line of at most 64 J pairs in LDS ranked by the whole wave, in place: every lane holds up to J pairs in registers,
+// counts the keys below each of them (the keys are read by all lanes together, eight loads in flight: LDS broadcasts) and
+// stores the pairs where they belong once every lane has read.  Ties keep their order; returns whether this lane saw a key
+// twice.
+template <int J> __device__ __forceinline__ int wave_rank_sort_lds(int *k, double *v, int n)
+{
+    const int lane = lane_id();
+    int kk[J], r[J];
+    double vv[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int q = lane + 64 * j;
+        kk[j] = q < n ? k[q] : 0x7fffffff;
+        vv[j] = q < n ? v[q] : 0.0;
+        r[j] = 0;
+    }
+    int dup = 0;
+    const auto rank_against = [&](int ku, int u) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const bool same = ku == kk[j] && u < lane + 64 * j;
+            r[j] += (ku < kk[j] || same) ? 1 : 0;
+            dup |= same ? 1 : 0;
+        }
+    };
+    int u = 0;
+    for (; u + 8 <= n; u += 8) {
+        const int k0 = k[u], k1 = k[u + 1], k2 = k[u + 2], k3 = k[u + 3], k4 = k[u + 4], k5 = k[u + 5], k6 = k[u + 6], k7 = k[u + 7];
+        rank_against(k0, u);
+        rank_against(k1, u + 1);
+        rank_against(k2, u + 2);
+        rank_against(k3, u + 3);
+        rank_against(k4, u + 4);
+        rank_against(k5, u + 5);
+        rank_against(k6, u + 6);
+        rank_against(k7, u + 7);
+    }
+    for (; u < n; u++) rank_against(k[u], u);
+    WAVE_LOCKSTEP(); // (every lane has read the keys)
+#pragma unroll
+    for (int j = 0; j < J; j++)
+        if (lane + 64 * j < n) {
+            k[r[j]] = kk[j];
+            v[r[j]] = vv[j];
+        }
+    WAVE_LOCKSTEP();
+    return dup;
+}
+
 // Phase B: bucket b.  extra(t, &key, &val): the entry a line ends with beyond its records (perline = 1), out(pos, key, val):
-// the store of output entry pos.  Lines of at most BKT_SSORT records leave sorted by key (ties in arrival order); longer
-// ones in arrival order.  Returns (per thread) whether a sorted line holds a key twice.
+// the store of output entry pos.  Lines of at most BKT_WSORT records leave sorted by key (ties in arrival order: up to
+// BKT_SSORT records by their thread, more by its wave); longer ones in arrival order.  Returns (per thread) whether a sorted
+// line holds a key twice.
 template <class Scope, class Extra, class Out>
 __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, gcint_p tstart, int nlines, int total, int perline,
                                              const BktRec *scr, Extra extra, Out out)
@@ -118,6 +171,7 @@ __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, 
     const int out0 = tstart[t0], out1 = t1 < nlines ? tstart[t1] : total;
     const int s0 = out0 - perline * t0, s1 = out1 - perline * t1;
     for (int i = tid; i < t1 - t0; i += nt) B.lcur[i] = tstart[t0 + i] - out0;
+    if (tid == 0) B.wl[0] = 0;
     sc.sync();
     for (int s = s0 + tid; s < s1; s += nt) {
         const BktRec r = scr[s];
@@ -163,6 +217,14 @@ __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, 
                 }
             }
         }
+        if (n > BKT_SSORT && n <= BKT_WSORT) B.wl[1 + atomicAdd(&B.wl[0], 1)] = lb * BKT_WSORT + (n - 1); // (at most span / 33 < 511 of them)
+    }
+    sc.sync();
+    // the longer lines, dealt out to the waves (they come in runs: the columns of the bump are neighbours)
+    const int nwl = __builtin_amdgcn_readfirstlane(B.wl[0]);
+    for (int e = wave_id(); e < nwl; e += num_waves()) {
+        const int w = __builtin_amdgcn_readfirstlane(B.wl[1 + e]), mlb = w / BKT_WSORT, mn = w % BKT_WSORT + 1; // (scalars)
+        dup |= mn <= 64 ? wave_rank_sort_lds<1>(B.lk + mlb, B.lv + mlb, mn) : wave_rank_sort_lds<4>(B.lk + mlb, B.lv + mlb, mn);
     }
     sc.sync();
     for (int q = tid; q < out1 - out0; q += nt) out(out0 + q, B.lk[q], B.lv[q]);

@@ -171,6 +171,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     const int m = D.m;
     if (S->status != ST_DONE) return;
     const int rank = S->rank;
+    FILL_STAMP_BEGIN();
 
     // ---- complete the permutations: unpivoted rows / columns in index order (build_factors.rs:192-209)
     for (int pass = 0; pass < 2; pass++) {
@@ -203,6 +204,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     }
     sc.sync();
 
+    FILL_STAMP(S, 8); // permutations
     // ---- L: column k = unit diagonal, then the stage-k column with rows renumbered by pinv and sorted
     // (get_factors.rs:86-113 scatters the row-wise copy in row order, which sorts each column)
     const int l_nz = D.lbeg[rank];
@@ -245,6 +247,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         else insertion_sort_pairs(O.l_rowidx, O.l_value, ob + 1, ob + 1 + (e - b));
     }
     sc.sync();
+    FILL_STAMP(S, 9); // L columns
     {
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -265,6 +268,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
     }
     sc.sync();
 
+    FILL_STAMP(S, 10); // L: medium and long columns
     // ---- U: column k collects the entries (stage k', column pcol[k]) of all U rows, ascending k'
     // (get_factors.rs:136-167); entries in columns that never became pivotal are dropped
     // (build_factors.rs:318-337, `qinv[j] < rank`)
@@ -339,6 +343,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         }
     }
     sc.sync();
+    FILL_STAMP(S, 11); // U: column counts
     int base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
         const int k = c0 + tid;
@@ -357,10 +362,11 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         *sc.ctr(0) = *sc.ctr(1) = 0;
     }
     sc.sync();
+    FILL_STAMP(S, 12); // U: column pointers
     // the fill of a batch in two phases (k_bucket.h): the records behind the targets in the workgroup's scratch
     bool bucketed = false;
     if (win && have_c) {
-        static_assert(BKT_SSORT == SSORT_MAX, "lines the buckets leave sorted = lines the pass below skips");
+        static_assert(BKT_WSORT == WSORT_MAX, "lines the buckets leave sorted = lines the pass below skips");
         Buckets BK = buckets_in(win, wincap);
         if (buckets_plan(sc, BK, D.iw1, m, u_tot)) {
             BktRec *scr = (BktRec *)(fscr + 4LL * unz4);
@@ -371,6 +377,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
                           if (a.g < rank) bucket_put(BK, scr, a.g, k, a.v);
                       });
             sc.sync();
+            FILL_STAMP(S, 13); // U: plan + phase A
             for (int b = 0; b < BK.nb; b++)
                 bucket_flush(
                     sc, BK, b, D.iw1, m, u_tot, 1, scr,
@@ -444,6 +451,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         }
     }
     sc.sync();
+    FILL_STAMP(S, 14); // U: phase B (or the window sweeps)
     double pmin = INFINITY, pmax = 0.0;
     for (int k = tid; k < m; k += nt) {
         const int b = (int)O.u_colptr[k], e = b + D.iw0[k];
@@ -455,12 +463,13 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         pmin = fmin(pmin, fabs(piv));
         pmax = fmax(pmax, fabs(piv));
         if (e - b > WSORT_MAX) D.iw2[m - 1 - atomicAdd(sc.ctr(1), 1)] = k;
-        else if (e - b > SSORT_MAX) D.iw2[atomicAdd(sc.ctr(0), 1)] = k;
         else if (bucketed) continue; // (sorted in LDS before it was written)
+        else if (e - b > SSORT_MAX) D.iw2[atomicAdd(sc.ctr(0), 1)] = k;
         else if (REGSORT) small_sort_pairs(O.u_rowidx, O.u_value, b, e);
         else insertion_sort_pairs(O.u_rowidx, O.u_value, b, e);
     }
     sc.sync();
+    FILL_STAMP(S, 15); // U: pivots, short columns
     {
         const int nmed = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nlong = __hip_atomic_load(sc.ctr(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -479,6 +488,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
             scope_sort_segment(sc, O.u_rowidx, O.u_value, b, b + D.iw0[k], m, (int *)D.iw1, (int *)D.tnewr, (int *)D.tnew, (double *)D.txrj);
         }
     }
+    FILL_STAMP(S, 16); // U: medium and long columns
     // min / max pivot (build_factors.rs:403-419): |pivots| are non-negative, so they order like their bit patterns
     const double amin = sc.min_d(pmin, shd), amax = sc.max_d(pmax, shd);
     if (sc.leader()) {

@@ -96,6 +96,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
     const int tid = sc.tid(), nt = sc.nt();
     const int m = D.m;
     if (S->status != ST_RUNNING) return;
+    FILL_STAMP_BEGIN();
 
     // ---- check pointers, count nnz(B), column pointers of the packed copy (singletons.rs:119-133)
     int bad = 0;
@@ -148,6 +149,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
     int ovf = 0;
     sc.sync();
 
+    FILL_STAMP(S, 0); // column pointers
     // ---- count nz per row, check indices, pack columns (singletons.rs:152-173)
     for (int j = tid; j < m; j += nt) {
         const unsigned long long b = D.b_begin[j], e = D.b_end[j];
@@ -210,6 +212,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         }
     }
 
+    FILL_STAMP(S, 1); // pack + row counts
     // ---- row pointers (singletons.rs:176-183)
     base = 0;
     for (int c0 = 0; c0 < m; c0 += nt) {
@@ -226,13 +229,14 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
     if (sc.leader()) D.bt_ptr[m] = base;
     sc.sync();
 
+    FILL_STAMP(S, 2); // row pointers
     // ---- fill rows in arbitrary order, then sort each row by column index: the reference fills
     // rows for j = 0..m-1 in turn (singletons.rs:186-198), i.e. ascending column inside a row.
     // a batch: in two phases through buckets (k_bucket.h); the 16-byte records go to the value array of the column arena
     // (nothing is in the arenas before k_setup)
     bool bucketed = false;
     if (win) {
-        static_assert(BKT_SSORT == 32, "rows the buckets leave sorted = rows the pass below skips");
+        static_assert(BKT_WSORT >= 48, "rows the buckets leave sorted (up to BKT_WSORT entries) cover the short rows of the pass below");
         Buckets BK = buckets_in(win, wincap);
         const bool room = 2LL * b_nz <= (long long)D.carena_cap; // (uniform)
         if (room && buckets_plan(sc, BK, D.iw1, m, b_nz)) {
@@ -242,6 +246,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
                 line4(D.bc_ptr[j], D.bc_ptr[j + 1], [&](int pos) { return IdxVal{D.bc_idx[pos], 0, D.bc_val[pos]}; },
                       [&](int, const IdxVal &a) { bucket_put(BK, scr, a.i, j, a.v); });
             sc.sync();
+            FILL_STAMP(S, 3); // fill: plan + phase A
             for (int b = 0; b < BK.nb; b++)
                 bad |= bucket_flush(
                     sc, BK, b, D.iw1, m, b_nz, 0, scr, [&](int, int *, double *) {},
@@ -280,17 +285,18 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
                       D.bt_val[p] = a.v;
                   });
     }
+    FILL_STAMP(S, 4); // fill: phase B (or the window sweeps)
     if (sc.leader()) *sc.ctr(0) = 0; // number of long rows
     sc.sync();
     // short rows: insertion sort by one thread; long rows (> 48): bitmap rank sort by the whole scope
     for (int i = tid; i < m; i += nt) {
         const int b = D.bt_ptr[i], e = D.bt_ptr[i + 1];
+        if (bucketed && e - b <= BKT_WSORT) continue; // (sorted and checked for duplicates in LDS before it was written)
         if (e - b > 48) {
             const int k = atomicAdd(sc.ctr(0), 1);
             D.iw2[k] = i; // list of long rows (order irrelevant)
             continue;
         }
-        if (bucketed && e - b <= 32) continue; // (sorted and checked for duplicates in LDS before it was written)
         if (REGSORT && e - b <= 16) {
             reg_sort_row<16>(D.bt_idx, D.bt_val, b, e - b);
         } else if (REGSORT && e - b <= 32) {
@@ -313,6 +319,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
             if (D.bt_idx[p] == D.bt_idx[p - 1]) bad = 1; // duplicate (singletons.rs:195-197)
     }
     sc.sync();
+    FILL_STAMP(S, 5); // rows of 33..48 entries, duplicates
     const int nlong = __hip_atomic_load(sc.ctr(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sc.sync();
     for (int r = 0; r < nlong; r++) {
@@ -354,6 +361,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         return;
     }
 
+    FILL_STAMP(S, 6); // long rows
     // ---- pivot singletons (singletons.rs:203-258), no cascade (D1)
     for (int i = tid; i < m; i += nt) {
         D.pinv[i] = -1;
@@ -502,6 +510,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         S->lused = lused;
         S->uused = uused;
     }
+    FILL_STAMP(S, 7); // singletons
 }
 // One workgroup per matrix AT A TIME: the grid is smaller than a large batch and each workgroup takes matrices
 // blockIdx.x, + gridDim.x, ... (blu_driver.inc: batch_grid).

@@ -392,6 +392,49 @@ def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch, window
         assert fills == [0] * 8 if window == 2048 else (all(f & 1 for f in fills) and sum(f == 3 for f in fills) >= 4), fills
 
 
+def test_bucket_fill_rows_of_every_length_and_duplicates(blu, oracle, monkeypatch):
+    """k_bucket.h sorts a target line where it sits in LDS -- up to 32 entries by one thread, up to 256 by its wave -- and
+    sees there whether a row of B holds a column twice (singletons.rs:195-197); longer rows leave in arrival order for the
+    sort of the whole workgroup.  A batch with a 48 KB window whose members have dense rows of 40, 150 and 300 entries
+    (all three regimes; slack of a bucket: 368), each once as it is and once with ONE entry repeated in such a row:
+    status and factors as the oracle has them."""
+    rng = np.random.default_rng(77)
+    m = 900
+    mats = []
+    for rowlen, dup in ((40, False), (40, True), (150, False), (150, True), (300, False), (300, True), (7, True)):
+        cp, ri, v = oracle.gen_lp_basis(m, 6, 8, 0.5, 11 + rowlen, 0.3)
+        cols = [list(zip(ri[cp[j]:cp[j + 1]].tolist(), v[cp[j]:cp[j + 1]].tolist())) for j in range(m)]
+        r = 450  # row r gets entries in `rowlen` columns
+        for j in rng.choice(m, rowlen, replace=False):
+            if all(i != r for i, _ in cols[j]):
+                cols[j].append((r, float(rng.uniform(0.1, 1.0))))
+        if dup:
+            j = next(j for j in range(m) if any(i == r for i, _ in cols[j]))
+            cols[j].append((r, 0.25))  # row r holds column j twice
+        ncp, nri, nv = [0], [], []
+        for j in range(m):
+            for i, x in cols[j]:
+                nri.append(i); nv.append(x)
+            ncp.append(len(nri))
+        mats.append((np.array(ncp, np.uint64), np.array(nri, np.uint64), np.array(nv)))
+    monkeypatch.setenv("BLU_BATCH_GRID", "2")
+    monkeypatch.setenv("BLU_LDS_WINDOW", "2")
+    monkeypatch.setenv("BLU_LDS_WINDOW_BYTES", "49152")
+    hs = [blu.BLU(m, len(ri)) for cp, ri, v in mats]
+    for name in ("BLU_BATCH_GRID", "BLU_LDS_WINDOW", "BLU_LDS_WINDOW_BYTES"):
+        monkeypatch.delenv(name)
+    sts = blu.blu.factorize_batch(hs, mats=mats)
+    for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
+        o = oracle.OracleBLU(m, 64 * len(ri))
+        o.set_fix_d3(True)
+        so = o.factorize(cp[:-1], cp[1:], ri, v)
+        assert sts[k] == so, (k, sts[k], so)
+        assert so == (K.ERROR_INVALID_ARGUMENT if k in (1, 3, 5, 6) else K.OK), (k, so)
+        assert int(h.stat(119)) & 1, k  # k_prep filled through buckets
+        if so == K.OK:
+            util.assert_same_factors(h.get_factors(), o.get_factors())
+
+
 @pytest.mark.parametrize("spec", [(3000, 9, 10, 0.4, 17, 0.4), (2500, 10, 9, 0.5, 1, 0.3), (1800, 6, 30, 0.1, 9, 1.0)],
                          ids=["mixed", "c3-like", "wide-band"])
 def test_one_wave_kernel_matches_workgroup_kernel_and_oracle(blu, oracle, spec):

@@ -30,3 +30,13 @@ for rep in range(reps):
            hs[0].stat(110), hs[0].stat(111), hs[0].stat(54), hs[0].stat(52)), "handed", hs[0].stat(116),
           "free mem %.1f GB" % (torch.cuda.mem_get_info()[0] / 1e9),
           "arena used c/r %d/%d of cap %d; L cap %d" % (max(h.stat(112) for h in hs), max(h.stat(113) for h in hs), hs[0].stat(114), hs[0].stat(115)), flush=True)
+if "fprof" in os.environ.get("BLU_HIP_LIB", ""):  # (make -C blu_amd/csrc fprof: shader-clock ticks per phase of k_prep / k_finish, summed over the batch)
+    names = ["prep: column pointers", "prep: pack + row counts", "prep: row pointers", "prep: fill, plan + phase A", "prep: fill, phase B / window sweeps",
+             "prep: rows of 33..48, duplicates", "prep: long rows", "prep: singletons", "finish: permutations", "finish: L columns",
+             "finish: L medium / long columns", "finish: U column counts", "finish: U column pointers", "finish: U fill, plan + phase A",
+             "finish: U fill, phase B / window sweeps", "finish: U pivots + short columns", "finish: U medium / long columns"]
+    tot = [sum(h.stat(60 + k) for h in hs) for k in range(len(names))]
+    for lo, hi, kern in ((0, 8, 0), (8, 17, 2)):
+        s = sum(tot[lo:hi])
+        for k in range(lo, hi):
+            print("  %-42s %5.1f %%  ~%.4f s of the kernel's %.3f s" % (names[k], 100 * tot[k] / s, ph[kern] * tot[k] / s, ph[kern]))
