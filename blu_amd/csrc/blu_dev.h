@@ -537,9 +537,18 @@ struct BlockScope {
     __device__ __forceinline__ long long sum_ll(long long v) { return block_sum_ll(v, shl); }
     __device__ __forceinline__ int any(int v) { return block_or_i(v, sh); }
     __device__ __forceinline__ int *ctr(int k) const { return &sh[34 + k]; } // k = 0..4; zero it, sync, then atomicAdd
-    // which share of the column / row count lists this wave builds (k_setup): wave 0 all column lists, wave 1 all row lists
+    // which share of the column / row count lists this wave builds (k_setup): up to three waves -- wave 0 all column lists,
+    // wave 1 all row lists
     __device__ __forceinline__ void list_roles(int &part, int &nparts, bool &cols, bool &rows) const
     {
+        const int nw = num_waves(), w = wave_id();
+        if (nw >= 4) { // (half of the waves the column lists, half the row lists, by key modulo their number)
+            nparts = nw / 2;
+            cols = w < nparts;
+            rows = w >= nparts && w < 2 * nparts;
+            part = cols ? w : w - nparts;
+            return;
+        }
         part = 0;
         nparts = 1;
         cols = wave_id() == 0;

@@ -19,21 +19,34 @@
 // ---------------------------------------------------------------------------------------------
 // The lists are independent of each other, so the waves of the scope share them out: wave `part` of `nparts`
 // builds the lists with key % nparts == part (every wave scans all elements; the keys are read coalesced).
-__device__ int wave_list_build(const LinkF &flink, const LinkB &blink, int n, gcint_p keys, int big, int part, int nparts)
+// ltail / kcap (a batch: LDS of the workgroup, or null): the tail of every list k < kcap lives in ltail[k] while the lists
+// are built and goes to its head, blink[n + k], at the end -- the tail is what every step of the build waits for (a
+// dependent round trip to L2 per distinct key of every 64 elements: 0.028 of the 0.081 s of k_setup for 1536 bases of
+// the 100k size), and the keys of an LP basis are line counts of a few entries.
+__device__ int wave_list_build(const LinkF &flink, const LinkB &blink, int n, gcint_p keys, int big, int part, int nparts, int *ltail = nullptr,
+                               int kcap = 0)
 {
     const int lane = lane_id();
     int minkey = big;
+    if (!ltail) kcap = 0;
+    for (int k = part + nparts * lane; k < kcap; k += nparts * 64) ltail[k] = n + k; // (empty: the head itself)
+    WAVE_LOCKSTEP();
+    int key_next = lane < n ? keys[lane] : -1;
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int e = c0 + lane;
-        int key = e < n ? keys[e] : -1;
+        const int key = key_next;
+        key_next = e + 64 < n ? keys[e + 64] : -1; // (in flight while this chunk is linked)
         bool act = key >= 0 && key % nparts == part;
         if (act && key > 0) minkey = min(minkey, key);
         unsigned long long active = __ballot(act);
+        bool through_memory = false;
         while (active) {
             const int leader = __ffsll((long long)active) - 1;
-            const int k = __shfl(key, leader);
+            const int k = wave_bcast_i(key, leader);
             const unsigned long long grp = __ballot(act && key == k);
-            const int tail = blink[n + k];
+            const bool inl = k < kcap; // (uniform)
+            const int tail = inl ? ltail[k] : blink[n + k];
+            through_memory = through_memory || !inl;
             WAVE_LOCKSTEP(); // (every lane has the old tail before the group's last lane replaces it)
             if (act && key == k) {
                 const unsigned long long below = grp & lanes_below(lane);
@@ -43,13 +56,19 @@ __device__ int wave_list_build(const LinkF &flink, const LinkB &blink, int n, gc
                 blink[e] = prevl >= 0 ? c0 + prevl : tail;
                 flink[e] = nextl >= 0 ? c0 + nextl : n + k;
                 if (prevl < 0) flink[tail] = e;
-                if (nextl < 0) blink[n + k] = e;
+                if (nextl < 0) {
+                    if (inl) ltail[k] = e;
+                    else blink[n + k] = e;
+                }
                 act = false;
             }
             active &= ~grp;
         }
-        wave_mem_sync(); // the next chunk reads blink[n+k] written here
+        if (through_memory) wave_mem_sync(); // the next chunk reads blink[n+k] written here
+        WAVE_LOCKSTEP();
     }
+    for (int k = part + nparts * lane; k < kcap; k += nparts * 64)
+        if (ltail[k] != n + k) blink[n + k] = ltail[k];
     return wave_min_i(minkey);
 }
 
@@ -569,6 +588,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
     const auto bm = [&](int e) { return (int)(((unsigned)win[e >> 5] >> (e & 31)) & 1u); };
     const auto row_g = [&](int i) { return usebm ? (bm(i) ? 0 : -1) : D.pinv[i]; }; // >= 0: row i is pivotal already
     const auto col_g = [&](int j) { return usebm ? bm(j) : D.iw0[j]; };             // > 0: column j is active
+    FILL_STAMP_BEGIN();
     if (usebm) build_bm([&](int e) { return D.pinv[e] >= 0; });
 
     // ---- columns: count, maximum, capacity (setup_bump.rs:131-186).  iw0[j] = list key:
@@ -614,6 +634,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         }
         base += tot;
     }
+    FILL_STAMP(S, 17); // setup: columns counted
     const int cused = base;
     dropped_nz = sc.sum_ll(dropped_nz);
     sc.sync();
@@ -629,6 +650,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
               });
     }
 
+    FILL_STAMP(S, 18); // setup: columns copied
     // ---- rows: pattern of the copied columns in ascending column order (setup_bump.rs:188-224)
     if (usebm) {
         sc.sync(); // (the column passes are done with the rows' bitmap)
@@ -661,6 +683,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         }
         base += tot;
     }
+    FILL_STAMP(S, 19); // setup: rows counted
     const int rused = base;
     sc.sync();
     for (int i = tid; i < m; i += nt) {
@@ -672,6 +695,7 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
               });
     }
 
+    FILL_STAMP(S, 20); // setup: rows copied
     // ---- count lists (setup_bump.rs:124-130, 188-194): list_init, then list_add in ascending index
     for (int e = tid; e < 2 * m + 2; e += nt) {
         D.cflink[e] = e;
@@ -691,19 +715,26 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         S->min_rownz = m + 2;
     }
     sc.sync();
+    FILL_STAMP(S, 21); // setup: lists and marks initialised
     { // the builder waves of the scope share out the lists (Scope::list_roles)
         int part, nparts;
         bool cols, rows;
         sc.list_roles(part, nparts, cols, rows);
+        // (a batch: the window -- its bitmaps are done with -- holds the tails of the lists of small keys, half of it each)
+        const int kcap = win ? min(wincap / 2, m + 2) : 0;
         if (cols) {
-            const int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2, part, nparts);
+            const int mn = wave_list_build(D.cflink, D.cblink, m, D.iw0, m + 2, part, nparts, win, kcap);
             if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_colnz, mn);
         }
         if (rows) {
-            const int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2, part, nparts);
+            const int mn = wave_list_build(D.rflink, D.rblink, m, D.iw1, m + 2, part, nparts, win ? win + wincap / 2 : nullptr, kcap);
             if (lane_id() == 0 && mn < m + 2) atomicMin(&S->min_rownz, mn);
         }
     }
+#ifdef BLU_PROFILE_FILLS
+    sc.sync(); // (the builder waves are done)
+#endif
+    FILL_STAMP(S, 22); // setup: count lists built
     if (sc.leader()) {
         const long long l_nz = S->lused, u_nz = S->uused;
         S->bump_nz = S->matrix_nz - l_nz - u_nz - rank - dropped_nz; // setup_bump.rs:89, :155

@@ -34,9 +34,11 @@ if "fprof" in os.environ.get("BLU_HIP_LIB", ""):  # (make -C blu_amd/csrc fprof:
     names = ["prep: column pointers", "prep: pack + row counts", "prep: row pointers", "prep: fill, plan + phase A", "prep: fill, phase B / window sweeps",
              "prep: rows of 33..48, duplicates", "prep: long rows", "prep: singletons", "finish: permutations", "finish: L columns",
              "finish: L medium / long columns", "finish: U column counts", "finish: U column pointers", "finish: U fill, plan + phase A",
-             "finish: U fill, phase B / window sweeps", "finish: U pivots + short columns", "finish: U medium / long columns"]
+             "finish: U fill, phase B / window sweeps", "finish: U pivots + short columns", "finish: U medium / long columns",
+             "setup: columns counted", "setup: columns copied", "setup: rows counted", "setup: rows copied", "setup: lists and marks initialised",
+             "setup: count lists built"]
     tot = [sum(h.stat(60 + k) for h in hs) for k in range(len(names))]
-    for lo, hi, kern in ((0, 8, 0), (8, 17, 2)):
+    for lo, hi, kern in ((0, 8, 0), (17, 23, 1), (8, 17, 2)):
         s = sum(tot[lo:hi])
         for k in range(lo, hi):
             print("  %-42s %5.1f %%  ~%.4f s of the kernel's %.3f s" % (names[k], 100 * tot[k] / s, ph[kern] * tot[k] / s, ph[kern]))
