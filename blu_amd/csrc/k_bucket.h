@@ -110,8 +110,8 @@ __device__ __forceinline__ void bucket_put(const Buckets &B, BktRec *scr, int t,
 // A line of at most 64 J pairs in LDS ranked by the whole wave, in place: every lane holds up to J pairs in registers,
 // counts the keys below each of them (the keys are read by all lanes together, eight loads in flight: LDS broadcasts) and
 // stores the pairs where they belong once every lane has read.  Ties keep their order; returns whether this lane saw a key
-// twice.
-template <int J> __device__ __forceinline__ int wave_rank_sort_lds(int *k, double *v, int n)
+// twice.  DUPS = false: the keys are known to be distinct (the columns of U).
+template <int J, bool DUPS> __device__ __forceinline__ int wave_rank_sort_lds(int *k, double *v, int n)
 {
     const int lane = lane_id();
     int kk[J], r[J];
@@ -127,9 +127,13 @@ template <int J> __device__ __forceinline__ int wave_rank_sort_lds(int *k, doubl
     const auto rank_against = [&](int ku, int u) {
 #pragma unroll
         for (int j = 0; j < J; j++) {
-            const bool same = ku == kk[j] && u < lane + 64 * j;
-            r[j] += (ku < kk[j] || same) ? 1 : 0;
-            dup |= same ? 1 : 0;
+            if (DUPS) {
+                const bool same = ku == kk[j] && u < lane + 64 * j;
+                r[j] += (ku < kk[j] || same) ? 1 : 0;
+                dup |= same ? 1 : 0;
+            } else {
+                r[j] += ku < kk[j] ? 1 : 0;
+            }
         }
     };
     int u = 0;
@@ -160,7 +164,7 @@ template <int J> __device__ __forceinline__ int wave_rank_sort_lds(int *k, doubl
 // the store of output entry pos.  Lines of at most BKT_WSORT records leave sorted by key (ties in arrival order: up to
 // BKT_SSORT records by their thread, more by its wave); longer ones in arrival order.  Returns (per thread) whether a sorted
 // line holds a key twice.
-template <class Scope, class Extra, class Out>
+template <bool DUPS, class Scope, class Extra, class Out>
 __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, gcint_p tstart, int nlines, int total, int perline,
                                              const BktRec *scr, Extra extra, Out out)
 {
@@ -208,9 +212,13 @@ __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, 
                     int r = 0;
 #pragma unroll
                     for (int j = 0; j < BKT_SSORT; j++) {
-                        const bool same = j < q && k[j] == k[q];
-                        r += (k[j] < k[q] || same) ? 1 : 0;
-                        dup |= same ? 1 : 0;
+                        if (DUPS) {
+                            const bool same = j < q && k[j] == k[q];
+                            r += (k[j] < k[q] || same) ? 1 : 0;
+                            dup |= same ? 1 : 0;
+                        } else {
+                            r += k[j] < k[q] ? 1 : 0;
+                        }
                     }
                     B.lk[lb + r] = k[q];
                     B.lv[lb + r] = v[q];
@@ -224,7 +232,7 @@ __device__ __forceinline__ int bucket_flush(Scope &sc, const Buckets &B, int b, 
     const int nwl = __builtin_amdgcn_readfirstlane(B.wl[0]);
     for (int e = wave_id(); e < nwl; e += num_waves()) {
         const int w = __builtin_amdgcn_readfirstlane(B.wl[1 + e]), mlb = w / BKT_WSORT, mn = w % BKT_WSORT + 1; // (scalars)
-        dup |= mn <= 64 ? wave_rank_sort_lds<1>(B.lk + mlb, B.lv + mlb, mn) : wave_rank_sort_lds<4>(B.lk + mlb, B.lv + mlb, mn);
+        dup |= mn <= 64 ? wave_rank_sort_lds<1, DUPS>(B.lk + mlb, B.lv + mlb, mn) : wave_rank_sort_lds<4, DUPS>(B.lk + mlb, B.lv + mlb, mn);
     }
     sc.sync();
     for (int q = tid; q < out1 - out0; q += nt) out(out0 + q, B.lk[q], B.lv[q]);

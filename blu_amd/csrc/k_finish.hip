@@ -379,7 +379,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
             sc.sync();
             FILL_STAMP(S, 13); // U: plan + phase A
             for (int b = 0; b < BK.nb; b++)
-                bucket_flush(
+                bucket_flush<false>(
                     sc, BK, b, D.iw1, m, u_tot, 1, scr,
                     [&](int t, int *key, double *val) { // pivot last
                         *key = t;

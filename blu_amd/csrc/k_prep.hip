@@ -267,7 +267,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
             sc.sync();
             FILL_STAMP(S, 3); // fill: plan + phase A
             for (int b = 0; b < BK.nb; b++)
-                bad |= bucket_flush(
+                bad |= bucket_flush<true>(
                     sc, BK, b, D.iw1, m, b_nz, 0, scr, [&](int, int *, double *) {},
                     [&](int pos, int key, double val) {
                         D.bt_idx[pos] = key;

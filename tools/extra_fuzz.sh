@@ -14,5 +14,8 @@ BLU_PIVOT_KERNEL=1 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 5)) 
 BLU_PIVOT_KERNEL=3 run python tools/fuzz_gpu.py --seed $((${SEED0:-40400} + 6)) --count 25 --mmin 3000 --mmax 20000
 run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 7)) --count 40
 BLU_PIVOT_KERNEL=1 run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 8)) --count 25
+# the fills through buckets (k_bucket.h): the LDS window forced on (a batch this small would run without), 32 KB and natural size
+BLU_LDS_WINDOW=2 BLU_LDS_WINDOW_BYTES=32768 BLU_BATCH_GRID=4 run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 10)) --count 40
+BLU_LDS_WINDOW=2 run python tools/fuzz_batch_gpu.py --seed $((${SEED0:-40400} + 11)) --count 30
 run python tools/fuzz_update_gpu.py --seed $((${SEED0:-40400} + 9)) --count 120
 cat $L
