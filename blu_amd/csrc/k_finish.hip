@@ -394,6 +394,7 @@ __device__ __forceinline__ void finish_body(const DevG &D, const FinishOut &O, S
         }
     }
     if (bucketed) {
+        // (filled above)
     } else if (win) { // column cursors in the LDS window
         for (int w0 = 0; w0 < rank; w0 += wincap) {
             const int wn = rank - w0 < wincap ? rank - w0 : wincap;

@@ -278,6 +278,7 @@ template <bool REGSORT, class Scope> __device__ __forceinline__ void prep_body(c
         }
     }
     if (bucketed) {
+        // (filled above)
     } else if (win) { // fill cursors in the LDS window
         for (int r0 = 0; r0 < m; r0 += wincap) {
             const int wn = m - r0 < wincap ? m - r0 : wincap;

@@ -2,6 +2,7 @@
 # The round's evidence in two GPU calls (outputs under gpurun_out/ev/; copied into profiles/ afterwards):
 #   bash tools/evidence.sh 1   bench lines of C3 (default run, with the batched legs), C2, C4, C5; rocprofv3 kernel stats of
 #                              the single C3 bench and of a C3 batch; the phase tables of the batch pivot kernels (prof build)
+#                              and of k_prep / k_setup / k_finish (fprof build)
 #   bash tools/evidence.sh 2   SQ counters of k_pivot_loop_wave2 / _wave; FETCH/WRITE_SIZE calibration; traffic of the pivot
 #                              kernels on every bench leg (profiles/pivot_loop_traffic.json, keyed by the hash of the kernel
 #                              sources); traffic of every kernel of a C3 batch step; L2 counters of the O(nnz) kernels
@@ -23,6 +24,7 @@ find $E/prof_b3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $E/batch_
 echo "kernel stats done"
 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 1536 C3 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c3.txt
 BLU_PIVOT_KERNEL=1 BLU_HIP_LIB=$R/blu_amd/libblu_hip_prof.so timeout -k 10 300 python tools/wave_phases.py 3072 C4 2>&1 | grep -v "amdgpu.ids\|k_stats chain" > $E/wave_phases_c4_onewave.txt
+BLU_HIP_LIB=$R/blu_amd/libblu_hip_fprof.so timeout -k 10 300 python tools/batch_probe.py 1536 256 C3 2 2 2>&1 | grep -v amdgpu.ids | tail -24 > $E/fill_phases_c3.txt
 rm -rf $E/prof_c3 $E/prof_b3
 else
 bash tools/batch_pmc.sh C2 4096 k_pivot_loop_wave 2 > $E/wave_sq_counters.txt 2>&1
