@@ -195,7 +195,9 @@ int blu_hip_update(blu_hip *h, double xtbl);
  * is refused: then every status[k] carries the refusal and no handle keeps usable factors).  The same
  * handle may not appear twice and all handles must live on one device (BLU_ERROR_INVALID_ARGUMENT).
  * Parameters and blu_hip_set_skip_stats are honoured per handle; the workgroup size of the batch
- * (a debug knob) is taken from h[0]. */
+ * (a debug knob) is taken from h[0].  Device memory: besides what the handles own, a call of at least one handle per
+ * CU borrows, for its duration, 20 bytes per U entry of its largest member for every CU (7.4 GB for bases of the
+ * 100k size) when that leaves at least 1 GB free; without it the same results take a little longer. */
 int blu_hip_factorize_batch(blu_hip **h, int n,
                             const uint64_t *const *b_begin, const uint64_t *const *b_end,
                             const uint64_t *const *b_i, const double *const *b_x,
