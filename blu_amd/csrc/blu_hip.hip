@@ -46,7 +46,9 @@
 using pv_single::k_pivot_loop;
 using pv_batch::k_pivot_loop_batch;
 using pv_wave::k_pivot_loop_wave;
+using pv_wave::k_pivot_loop_wave_r3;
 using pv_wave2::k_pivot_loop_wave2;
+using pv_wave2::k_pivot_loop_wave2_r3;
 #include "k_prep.hip"
 #include "k_solve.hip"
 #include "k_solve_sparse.hip"
@@ -121,10 +123,11 @@ struct blu_hip {
     int skip_stats;    // 1: do not compute condest / residual_test inside factorize (keys return 0)
     GridWs *gw;        // scratch of the chip-wide O(nnz) phases (single-basis path)
     int grid_blocks;   // workgroups of their cooperative launches (0/1: one workgroup, as in a batch)
-    int last_pivot_kernel;
+    int last_pivot_kernel, last_pivot_regs; // (statistics 118, 120)
     int lds_window, lds_window_mode; // bytes of dynamic LDS the batch forms of k_prep / k_finish may use as a counter window (0: not available), and when (env BLU_LDS_WINDOW)
     int num_cus, batch_grid; // CUs of the device; workgroups of k_prep / k_setup / k_finish in a batch (0: one per CU; env BLU_BATCH_GRID)
     int wave2_max;     // bases the card holds at once with TWO waves each (k_pivot_loop_wave2): a batch up to this size takes that kernel
+    int wave2_r3_max, wave_r3_max; // ... and what it holds of the variants with the registers of three waves per SIMD (_r3)
     std::string err;
     int64_t stop_at;   // debug: -1 off
 };
@@ -351,6 +354,12 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
         if (!prop.cooperativeLaunch) h->grid_blocks = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave2, 128, 0) != hipSuccess) nb = 0;
         h->wave2_max = nb * prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave2_r3, 128, 0) != hipSuccess) nb = 0;
+        h->wave2_r3_max = nb * prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pivot_loop_wave_r3, 64, 0) != hipSuccess) nb = 0;
+        h->wave_r3_max = nb * prop.multiProcessorCount;
+        if (const char *pr = getenv("BLU_PIVOT_REGS")) // (diagnostic) 4: never the _r3 variants
+            if (atoi(pr) == 4) h->wave2_r3_max = h->wave_r3_max = 0;
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
         {   // 144 KB of the CU's 160 KB as the counter window of k_prep / k_finish in a large batch.  Diagnostics:
             // BLU_LDS_WINDOW = 0 never, 1 (default) a batch of at least one basis per CU, 2 every batch;
@@ -522,6 +531,7 @@ extern "C" double blu_hip_get_stat(const blu_hip *h, int key)
     case 113: return (double)s.rused;
     case 114: return (double)h->D.carena_cap;
     case 115: return (double)h->D.lcap;
+    case 120: return (double)h->last_pivot_regs; // waves per SIMD its register budget was set for (the _r3 variants of the wave kernels: 3; else 4)
     case 118: return (double)h->last_pivot_kernel; // which pivot kernel the last factorize of this handle ran: 0 k_pivot_loop, 1 k_pivot_loop_wave, 2 k_pivot_loop_batch, 3 k_pivot_loop_wave2
     case 119: return (double)s.fill_paths; // bit 0 / bit 1: k_prep / k_finish filled through buckets (k_bucket.h)
     case 57: return (double)s.err_line;

@@ -74,6 +74,7 @@ def _batch_as_benched(blu, oracle, cfg, n, nseeds, step, expect_kernel, allow_d3
         sts = blu.factorize_batch(hs, mats=member_mats)  # no debug environment, default dispatch
         assert all(s == K.OK for s in sts), (what, [(k, s) for k, s in enumerate(sts) if s != K.OK][:8])
         assert int(hs[0].stat(118)) == expect_kernel and int(hs[-1].stat(118)) == expect_kernel, what
+        assert int(hs[0].stat(120)) == 3, what  # (all workgroups resident with the registers of three waves per SIMD: the _r3 variant)
         if what == "hint nnz/2":  # as benched: k_prep and k_finish fill through buckets (k_bucket.h; statistic 119)
             assert all(int(h.stat(119)) == 3 for h in hs), what
         for k in sample:

@@ -180,7 +180,10 @@ def test_fuzz_slice_one_wave_kernel_forced(args, tag):
     os.makedirs(out, exist_ok=True)
     log = os.path.join(out, "fuzz_wave_s%s.log" % args[1])
     cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py")] + args + ["--log", log]
-    text = _run_slice(cmd, log, "one-wave slice", env=dict(os.environ, BLU_PIVOT_KERNEL="1"))
+    # ("mid" with BLU_PIVOT_REGS=4: the variant of the kernel with the register budget of four waves per SIMD, what a batch of
+    # more than 3072 bases runs; "small" takes the _r3 variant like every batch that is resident at three)
+    env = dict(os.environ, BLU_PIVOT_KERNEL="1", **({"BLU_PIVOT_REGS": "4"} if "--mmin" in args else {}))
+    text = _run_slice(cmd, log, "one-wave slice", env=env)
     assert tag in text
 
 

@@ -328,9 +328,14 @@ def test_generators_agree(blu, oracle):
             assert np.array_equal(x, y)
 
 
-def test_batch_of_independent_bases(blu, oracle):
+@pytest.mark.parametrize("regs", [3, 4])
+def test_batch_of_independent_bases(blu, oracle, monkeypatch, regs):
     """blu_hip_factorize_batch: one workgroup per handle, all kernels launched once for the batch.
-    Mixed sizes, one singular and one invalid member; every member must equal its own oracle run."""
+    Mixed sizes, one singular and one invalid member; every member must equal its own oracle run.
+    regs: the wave kernels exist with the register budget of three waves per SIMD (`_r3`: what a batch whose workgroups
+    are all resident at that budget runs -- any batch this small) and of four (BLU_PIVOT_REGS=4 here; statistic 120)."""
+    if regs == 4:
+        monkeypatch.setenv("BLU_PIVOT_REGS", "4")
     specs = [(300, 5, 4, 0.5, 1, 0.3), (1200, 8, 8, 0.5, 2, 0.3), (50, 4, 3, 0.5, 3, 0.3), (2000, 8, 8, 0.5, 4, 0.3),
              (700, 6, 6, 1.0, 5, 0.2), (900, 7, 8, 0.5, 21, 0.4), (400, 6, 6, 0.0, 13, 0.5), (1500, 8, 16, 0.2, 3, 1.0)]
     mats = [list(oracle.gen_lp_basis(*s)) for s in specs]
@@ -340,8 +345,10 @@ def test_batch_of_independent_bases(blu, oracle):
     mats[2][1] = mats[2][1].copy()
     mats[2][1][5] = 50  # invalid member: row index out of range
     hs = [blu.BLU(len(m[0]) - 1, len(m[1]) if k != 7 else 16) for k, m in enumerate(mats)]  # member 7 starts far too small
+    monkeypatch.delenv("BLU_PIVOT_REGS", raising=False)
     for block in (256, 64, 1024):
         sts = blu.blu.factorize_batch(hs, mats=[tuple(m) for m in mats], block=block)
+        assert int(hs[0].stat(118)) == 3 and int(hs[0].stat(120)) == regs
         for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
             o, so = util.oracle_factorize(oracle, cp, ri, v, cap=64 * len(ri), allow_d3=(k == 7))  # member 7 hits D3 once
             assert sts[k] == so, (k, sts[k], so)
