@@ -373,7 +373,8 @@ extern "C" blu_hip *blu_hip_new(int64_t m, int64_t b_nz, int device)
                 hipFuncSetAttribute((const void *)k_finish<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
                 hipFuncSetAttribute((const void *)k_prep<512>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
                 hipFuncSetAttribute((const void *)k_finish<512>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
-                hipFuncSetAttribute((const void *)k_setup, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
+                hipFuncSetAttribute((const void *)k_setup<512>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_setup<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
                 h->lds_window = want;
             if (lb && h->lds_window) {
                 const int v = atoi(lb) & ~15;

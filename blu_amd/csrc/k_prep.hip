@@ -747,7 +747,8 @@ template <class Scope> __device__ __forceinline__ void setup_body(const DevG &D,
         S->rankdef = 0;
     }
 }
-__global__ void __launch_bounds__(1024) k_setup(DevLU *Ds, int nmat, int winbytes)
+// NT = threads of the workgroup at most (512: a batch -- the register budget of two waves per SIMD; 1024 otherwise)
+template <int NT> __global__ void __launch_bounds__(NT) k_setup(DevLU *Ds, int nmat, int winbytes)
 {
     __shared__ int sh[40];
     __shared__ long long shl[20];
