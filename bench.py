@@ -177,6 +177,7 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
     F = sum(h.stat(K.STAT_FACTOR_FLOPS) for h in hs)
     lu = sum(h.stat(K.STAT_L_NZ) + h.stat(K.STAT_U_NZ) for h in hs)
     which = int(hs[0].stat(118))  # the pivot kernel the library chose (blu_driver.inc: batch_pivot_and_finish)
+    regs = int(hs[0].stat(120))   # ... and its register budget in waves per SIMD (3: the _r3 variant of a wave kernel)
     fast_share = (sum(h.stat(110) + h.stat(111) for h in hs[:64])) / max(1.0, sum(h.stat(52) + h.stat(54) for h in hs[:64]))
     el = shard.max_over_ranks(med[0], dev)
     t_piv, nl, hs_phase = med[1], med[2], med[3]
@@ -205,7 +206,7 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
             "flattened_path_share": fast_share, "verified_members": verified,
             "verified_against": "CPU oracle, untimed, after the timed steps: members %s -- integer arrays, values, counters, "
                                 "pivots per routine, statistics bit-identical" % (sample,),
-            "roofline": {"bound": "hbm", "kernel": "%s (grid = %d workgroups)" % (kname, B), "achieved": gbs,
+            "roofline": {"bound": "hbm", "kernel": "%s%s (grid = %d workgroups)" % (kname, "_r3" if regs == 3 and which in (1, 3) else "", B), "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic},
             "note": "throughput mode, reported beside the headline; `value` above is ONE basis per GPU"}
 
