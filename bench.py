@@ -179,6 +179,12 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
     which = int(hs[0].stat(118))  # the pivot kernel the library chose (blu_driver.inc: batch_pivot_and_finish)
     regs = int(hs[0].stat(120))   # ... and its register budget in waves per SIMD (3: the _r3 variant of a wave kernel)
     fast_share = (sum(h.stat(110) + h.stat(111) for h in hs[:64])) / max(1.0, sum(h.stat(52) + h.stat(54) for h in hs[:64]))
+    # the O(nnz) kernels of the step by the same algorithmic bytes as the single-basis line, summed
+    # over the bases of the launch
+    m_ = c["m"]
+    bump = sum(h.stat(K.STAT_BUMP_NZ) for h in hs)
+    onnz_bytes = {"k_prep": 16.0 * (nnz + B * m_) + 16.0 * nnz, "k_setup": 16.0 * nnz + 24.0 * bump + 32.0 * B * (2 * m_ + 2),
+                  "k_finish": 16.0 * lu + 16.0 * (lu + 2 * B * m_) + 16.0 * B * m_}
     el = shard.max_over_ranks(med[0], dev)
     t_piv, nl, hs_phase = med[1], med[2], med[3]
     gbs = (32.0 * F + 32.0 * lu) / t_piv / 1e9
@@ -203,6 +209,10 @@ def batched_throughput(args, c, dev, local_rank, world, be, B=None, cfg_name=Non
                                 "note": "handles created with hint nnz/2: storage growth, compaction rounds and relaunches included"},
             "pivot_kernel_seconds": t_piv, "pivot_kernel_launches": nl,
             "phases_seconds": {"k_prep": hs_phase[0], "k_setup": hs_phase[1], "k_finish": hs_phase[2], "k_stats": hs_phase[3]},
+            "roofline_onnz_kernels": {k: {"bound": "hbm", "achieved": onnz_bytes[k] / max(hs_phase[i], 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": onnz_bytes[k] / max(hs_phase[i], 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_launch": onnz_bytes[k], "seconds": hs_phase[i]}
+                                      for i, k in enumerate(("k_prep", "k_setup", "k_finish"))},
             "flattened_path_share": fast_share, "verified_members": verified,
             "verified_against": "CPU oracle, untimed, after the timed steps: members %s -- integer arrays, values, counters, "
                                 "pivots per routine, statistics bit-identical" % (sample,),
