@@ -6,6 +6,8 @@
 #   bash tools/evidence.sh 2   SQ counters of k_pivot_loop_wave2 / _wave; FETCH/WRITE_SIZE calibration; traffic of the pivot
 #                              kernels on every bench leg (profiles/pivot_loop_traffic.json, keyed by the hash of the kernel
 #                              sources); traffic of every kernel of a C3 batch step; L2 counters of the O(nnz) kernels
+# Before the call (in the container; the built libraries travel with the snapshot): python -c 'import __graft_entry__ as g; g.build()'
+# and make -C blu_amd/csrc prof fprof.  Afterwards: copy gpurun_out/ev/* into profiles/ (names as in BASELINE.md section 9).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 E=$R/gpurun_out/ev
 mkdir -p $E
