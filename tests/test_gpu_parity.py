@@ -399,11 +399,67 @@ def test_batch_with_fewer_workgroups_than_bases(blu, oracle, monkeypatch, window
         assert fills == [0] * 8 if window == 2048 else (all(f & 1 for f in fills) and sum(f == 3 for f in fills) >= 4), fills
 
 
+def test_byte_counter_overflow_and_long_u_columns(blu, oracle, monkeypatch):
+    """The one-byte counters of k_prep / k_finish (one LDS window for every line of the matrix) give up at 255 entries
+    in a line and the matrix takes the 32-bit windows; a U column longer than a bucket's slack takes the window fill.
+    Arrow-like bases -- a band plus dense last columns, so U ends in columns of several hundred entries and B has rows
+    of 2-3 entries only, and the transposed shape (dense last ROWS: k_prep's counters overflow, U stays short) -- in a
+    batch with a 48 KB window, against the oracle; statistic 119 tells which fill each kernel took."""
+    rng = np.random.default_rng(5)
+    m = 800
+    mats = []
+    for transposed in (False, True, False):
+        ndense = 3 if len(mats) < 2 else 1
+        cols = [[(j, 2.0 + float(rng.uniform(0, 1)))] + ([(j - 1, float(rng.uniform(-0.5, 0.5)))] if j else []) for j in range(m)]
+        for d in range(ndense):
+            jd = m - 1 - d
+            for i in rng.choice(m - 10, 400 - 60 * d, replace=False):
+                if transposed:  # dense ROW jd
+                    if all(r != jd for r, _ in cols[int(i)]):
+                        cols[int(i)].append((jd, float(rng.uniform(-0.3, 0.3))))
+                elif all(r != int(i) for r, _ in cols[jd]):  # dense COLUMN jd
+                    cols[jd].append((int(i), float(rng.uniform(-0.3, 0.3))))
+        cp, ri, v = [0], [], []
+        for j in range(m):
+            for i, x in cols[j]:
+                ri.append(i); v.append(x)
+            cp.append(len(ri))
+        mats.append((np.array(cp, np.uint64), np.array(ri, np.uint64), np.array(v)))
+    monkeypatch.setenv("BLU_BATCH_GRID", "2")
+    monkeypatch.setenv("BLU_LDS_WINDOW", "2")
+    monkeypatch.setenv("BLU_LDS_WINDOW_BYTES", "49152")
+    hs = [blu.BLU(m, len(ri)) for cp, ri, v in mats]
+    for name in ("BLU_BATCH_GRID", "BLU_LDS_WINDOW", "BLU_LDS_WINDOW_BYTES"):
+        monkeypatch.delenv(name)
+    sts = blu.blu.factorize_batch(hs, mats=mats)
+    fills = []
+    for k, (h, (cp, ri, v)) in enumerate(zip(hs, mats)):
+        o, so = util.oracle_factorize(oracle, cp, ri, v, allow_d3=True)
+        assert sts[k] == so == K.OK, (k, sts[k], so)
+        util.assert_same_factors(h.get_factors(), o.get_factors())
+        for c in util.COUNTERS:
+            assert int(h.stat(getattr(K, "STAT_" + c))) == int(o.stat(getattr(K, "STAT_" + c))), (k, c)
+        for c in FSTATS + ("RESIDUAL_TEST", "MIN_PIVOT", "MAX_PIVOT"):
+            if k == 1 and c in ("INFNORM", "RESIDUAL_TEST"):
+                # rows of more than 256 entries: k_stats_tail sums them in storage order, the reference in pivot order of their
+                # columns (DESIGN.md section 4, statistics tail): equal to rounding, and the residual is rounding noise itself
+                if c == "INFNORM":
+                    assert abs(h.stat(K.STAT_INFNORM) - o.stat(K.STAT_INFNORM)) <= 1e-13 * o.stat(K.STAT_INFNORM), k
+                continue
+            assert h.stat(getattr(K, "STAT_" + c)) == o.stat(getattr(K, "STAT_" + c)), (k, c)
+        fills.append(int(h.stat(119)))
+        ucol = np.diff(o.get_factors()["u_colptr"]).max()
+        brow = np.bincount(ri.astype(np.int64), minlength=m).max()
+        assert (ucol > 336) == (not fills[-1] & 2), (k, ucol, fills)  # (slack of a bucket at this window: 336 entries, pivot included)
+        assert (brow > 336) == (not fills[-1] & 1), (k, brow, fills)
+    assert 0 in [f & 2 for f in fills] and 0 in [f & 1 for f in fills], fills  # both fallbacks were taken by some member
+
+
 def test_bucket_fill_rows_of_every_length_and_duplicates(blu, oracle, monkeypatch):
     """k_bucket.h sorts a target line where it sits in LDS -- up to 32 entries by one thread, up to 256 by its wave -- and
     sees there whether a row of B holds a column twice (singletons.rs:195-197); longer rows leave in arrival order for the
     sort of the whole workgroup.  A batch with a 48 KB window whose members have dense rows of 40, 150 and 300 entries
-    (all three regimes; slack of a bucket: 368), each once as it is and once with ONE entry repeated in such a row:
+    (all three regimes; slack of a bucket: 336), each once as it is and once with ONE entry repeated in such a row:
     status and factors as the oracle has them."""
     rng = np.random.default_rng(77)
     m = 900
